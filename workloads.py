@@ -1,0 +1,207 @@
+"""Seeded synthetic instances of the BASELINE.json configurations.
+
+Shared by tests/, tests/golden/make_golden.py and bench.py.  Pure numpy/scipy;
+no dependency on the product package or on the oracle.
+
+  c1  afiro-size LP            m=27,   n=51
+  c2  random sparse LP         m=2e4,  n=1e5, 20 nnz/col
+  c3  OT on the 28x28 grid     S=D=784
+  c4  GOTO-like MCF            V=2^17, E=2^20
+  c5  netlib-style LP          m=1e6,  n=1e7, 8 nnz/col
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+
+@dataclass
+class LPInstance:
+    A: sp.csr_matrix          # m x n, CSR, sorted indices, no duplicates
+    b: np.ndarray
+    c: np.ndarray
+    l: np.ndarray
+    u: np.ndarray
+    sense: np.ndarray         # '=' / '<'
+    x: np.ndarray             # synthetic interior primal point
+    y: np.ndarray             # synthetic interior dual point
+    name: str = "synthetic_lp"
+
+
+def _stratified_rows(rng, m: int, n: int, k: int) -> np.ndarray:
+    """k distinct ascending rows per column: one uniform pick in each of k
+    equal strata of [0, m).  Shape (n, k), int32."""
+    width = m // k
+    base = (np.arange(k, dtype=np.int64) * width)[None, :]
+    pick = rng.integers(0, width, size=(n, k), dtype=np.int64)
+    return (base + pick).astype(np.int32)
+
+
+def _sampled_rows(rng, m: int, n: int, k: int) -> np.ndarray:
+    """k distinct ascending rows per column drawn without replacement
+    (argpartition of random keys); only for small m*n."""
+    keys = rng.random((n, m))
+    rows = np.argpartition(keys, k - 1, axis=1)[:, :k]
+    return np.sort(rows, axis=1).astype(np.int32)
+
+
+def sparse_lp(m: int, n: int, nnz_per_col: int, seed: int, frac_lt: float = 0.5,
+              frac_upper: float = 0.25, frac_free: float = 0.0, stratified: Optional[bool] = None,
+              name: str = "synthetic_lp") -> LPInstance:
+    """Random sparse LP with a synthetic interior point (x, y) shaped like a
+    late barrier iterate: m random columns are
+    "basic" (x in U(0.1, 1), dual slack ~1e-10), the others sit 1e-9 away from
+    a bound with a dual slack |N(0,1)|; y ~ N(0,1); a ``frac_lt`` share of the
+    rows is '<', and of those the ones with y < 0 are tight.
+    """
+    rng = np.random.default_rng(seed)
+    k = nnz_per_col
+    if stratified is None:
+        stratified = m * n > 5_000_000
+    rows = _stratified_rows(rng, m, n, k) if stratified else _sampled_rows(rng, m, n, k)
+    vals = rng.uniform(-1.0, 1.0, size=(n, k))
+    vals[np.abs(vals) < 1e-3] = 0.5
+    colptr = np.arange(n + 1, dtype=np.int64) * k
+    C = sp.csc_matrix((vals.ravel(), rows.ravel(), colptr), shape=(m, n))
+    A = C.tocsr()
+    A.sort_indices()
+
+    y = rng.standard_normal(m)
+    sense = np.where(rng.random(m) < frac_lt, "<", "=")
+    # for '<' rows the dual must be <= 0 in "min c^T x, Ax <= b"; keep the sign
+    # random so that both tight (y<0) and slack (y~0) rows appear
+    lt = sense == "<"
+    y[lt] = np.where(rng.random(int(lt.sum())) < 0.5, -np.abs(y[lt]), 1e-11 * np.abs(y[lt]))
+
+    l = np.zeros(n)
+    u = np.full(n, np.inf)
+    has_up = rng.random(n) < frac_upper
+    u[has_up] = rng.uniform(1.0, 10.0, int(has_up.sum()))
+    if frac_free > 0:
+        free = rng.random(n) < frac_free
+        l[free] = -np.inf
+        u[free] = np.inf
+
+    basic = np.zeros(n, dtype=bool)
+    basic[rng.choice(n, size=min(m, n), replace=False)] = True
+    x = np.full(n, 1e-9)
+    x[basic] = rng.uniform(0.1, 1.0, int(basic.sum()))
+    at_up = (~basic) & has_up & (rng.random(n) < 0.5)
+    x[at_up] = u[at_up] - 1e-9
+
+    s_d = np.abs(rng.standard_normal(n))
+    s_d[basic] = 1e-10 * rng.random(int(basic.sum()))
+    s_d[at_up] = -s_d[at_up]
+    c = A.T @ y + s_d
+
+    slack = np.zeros(m)
+    loose = lt & (y > -1e-9)
+    slack[loose] = rng.uniform(0.1, 1.0, int(loose.sum()))
+    tight = lt & ~loose
+    slack[tight] = 1e-10 * rng.random(int(tight.sum()))
+    b = A @ x + slack
+    return LPInstance(A=A, b=b, c=c, l=l, u=u, sense=sense, x=x, y=y, name=name)
+
+
+def config1(seed: int = 2024) -> LPInstance:
+    """afiro-size: m=27, n=51, 2 nnz/col (~102 nnz), entries from {+-1, 2, 0.5}."""
+    inst = sparse_lp(27, 51, 2, seed, frac_lt=0.4, frac_upper=0.3, stratified=False, name="afiro_size")
+    rng = np.random.default_rng(seed + 1)
+    A = inst.A.copy()
+    A.data = rng.choice(np.array([1.0, -1.0, 2.0, 0.5]), size=A.nnz)
+    # rebuild c and b so that (x, y) keeps its interior-point shape
+    s_d = inst.c - inst.A.T @ inst.y
+    slack = inst.b - inst.A @ inst.x
+    return LPInstance(A=A, b=A @ inst.x + slack, c=A.T @ inst.y + s_d, l=inst.l, u=inst.u, sense=inst.sense,
+                      x=inst.x, y=inst.y, name="afiro_size")
+
+
+def config2(seed: int = 2) -> LPInstance:
+    return sparse_lp(20_000, 100_000, 20, seed, stratified=True, name="c2_2e4x1e5")
+
+
+def config5(seed: int = 5, n: int = 10_000_000, m: int = 1_000_000) -> LPInstance:
+    return sparse_lp(m, n, 8, seed, stratified=True, name="c5_1e6x1e7")
+
+
+# --------------------------------------------------------------------------
+@dataclass
+class MCFInstance:
+    A: sp.csr_matrix          # V x E incidence: +1 at the tail, -1 at the head (scripts/min2mcf.py convention)
+    b: np.ndarray
+    c: np.ndarray
+    u: np.ndarray
+    x: np.ndarray             # inexact interior flow
+    tail: np.ndarray
+    head: np.ndarray
+    name: str = "synthetic_mcf"
+
+
+def mcf(V: int, E: int, seed: int = 3, frac_interior: float = 0.15) -> MCFInstance:
+    """GOTO-like min-cost-flow instance."""
+    rng = np.random.default_rng(seed)
+    tail = rng.integers(0, V, size=E, dtype=np.int64)
+    head = (tail + rng.integers(1, V, size=E, dtype=np.int64)) % V
+    u = rng.integers(1, 1000, size=E).astype(np.float64)
+    c = rng.integers(1, 10000, size=E).astype(np.float64)
+    x = np.empty(E)
+    interior = rng.random(E) < frac_interior
+    x[interior] = rng.uniform(0.01, 0.99, int(interior.sum())) * u[interior]
+    near_up = (~interior) & (rng.random(E) < 0.3)
+    near_lo = (~interior) & ~near_up
+    x[near_lo] = 1e-7 * u[near_lo] * rng.random(int(near_lo.sum()))
+    x[near_up] = u[near_up] * (1 - 1e-7 * rng.random(int(near_up.sum())))
+    arc = np.arange(E, dtype=np.int64)
+    A = sp.csr_matrix((np.concatenate([np.ones(E), -np.ones(E)]),
+                       (np.concatenate([tail, head]), np.concatenate([arc, arc]))), shape=(V, E))
+    A.sort_indices()
+    b = A @ x
+    b[-1] -= b.sum()          # exact balance up to one rounding
+    return MCFInstance(A=A, b=b, c=c, u=u, x=x, tail=tail, head=head, name=f"mcf_{V}x{E}")
+
+
+def config4(seed: int = 3) -> MCFInstance:
+    return mcf(2 ** 17, 2 ** 20, seed)
+
+
+# --------------------------------------------------------------------------
+@dataclass
+class OTInstance:
+    s: np.ndarray
+    d: np.ndarray
+    M: np.ndarray
+    x: np.ndarray             # flattened S*D inexact plan (Sinkhorn-like scaling sweeps)
+    name: str = "synthetic_ot"
+
+
+def grid_cost(side: int) -> np.ndarray:
+    """Manhattan distance between the cells of a side x side grid (the cost
+    scripts/mnist2ot.py builds for k = 1)."""
+    r, cc = np.divmod(np.arange(side * side), side)
+    return (np.abs(r[:, None] - r[None, :]) + np.abs(cc[:, None] - cc[None, :])).astype(np.float64)
+
+
+def ot(S: int, D: int, seed: int = 7, sweeps: int = 50, M: Optional[np.ndarray] = None) -> OTInstance:
+    rng = np.random.default_rng(seed)
+    if M is None:
+        M = rng.integers(1, 50, size=(S, D)).astype(np.float64)
+    s = rng.random(S) + 0.05
+    d = rng.random(D) + 0.05
+    s /= s.sum()
+    d /= d.sum()
+    d[-1] += s.sum() - d.sum()
+    K = np.exp(-M / 3.0)
+    a = np.ones(S)
+    bb = np.ones(D)
+    for _ in range(sweeps):
+        a = s / (K @ bb)
+        bb = d / (K.T @ a)
+    X = a[:, None] * K * bb[None, :]
+    return OTInstance(s=s, d=d, M=M, x=X.ravel(), name=f"ot_{S}x{D}")
+
+
+def config3(seed: int = 7) -> OTInstance:
+    return ot(784, 784, seed, M=grid_cost(28))
