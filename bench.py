@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the crossover scoring pass on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one primal-dual indicator scoring pass of ``get_perturb_problem``
+(reference lp_methods/algorithms.py:99-106) plus the pricing reduction, over the
+LP resident in HBM:
+    K1  sx_score_columns   s_d = c - A^T y, column codes        (this rank's column block)
+    K2  sx_score_rows      s_p = b - A x,  row flags            (this rank's row block)
+        sx_select_indices  x3: fix_low, fix_up, fixed_rows      (np.where of the reference)
+    K10 sx_price           min reduced cost + violation count   (this rank's column block)
+    N>1: one RCCL all-gather of the 24-byte pricing records + one all-reduce(SUM) of the
+         three set sizes (the only exchange the column-sharded path needs).
+Workload (weak scaling): rank r owns column block r (m x n_block, CSC) and row block r
+(m/N x N*n_block, CSR) of one global LP; default c5 = BASELINE.json configs[4] per GPU
+(m=1e6, n_block=1e7, 8 nnz/col, 1.46 GB of algorithmic bytes for K1 alone -- far beyond the
+256 MiB Infinity Cache, so HBM GB/s is honest).  ``--workload c2`` runs configs[1]
+(2e4 x 1e5, cache resident).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` for
+sx_score_columns (HIP-event timed inside the timed region) and ``cpu_baseline`` (the numpy/scipy
+oracle timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
+
+import workloads  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X nominal HBM3E bandwidth (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name: (m, n_block, nnz/col, description)
+    "c5": (1_000_000, 10_000_000, 8, "synthetic netlib-style LP, 1e6 rows x 1e7 cols per GPU, 8 nnz/col, CSC+CSR"),
+    "c2": (20_000, 100_000, 20, "synthetic random sparse LP, 2e4 rows x 1e5 cols, 20 nnz/col (cache resident)"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    from smart_crossover.hip import Context   # raises if libsxhip.so is missing: no CPU fallback
+
+    dist = None
+    torch = None
+    stream = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        stream = torch.cuda.current_stream().cuda_stream
+    ctx = Context(local_rank, stream)
+    dev_name, cus, hbm = ctx.device_info()
+
+    m, n_block, k, desc = WORKLOADS[args.workload]
+    t0 = time.time()
+    if m % k or k % world:
+        raise SystemExit(f"workload {args.workload}: world={world} must divide nnz/col={k}")
+    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5)
+    if rank == 0:
+        log(f"[bench] generated shard in {time.time() - t0:.1f}s: col block {sh.col_block.shape} nnz={sh.col_block.nnz}, "
+            f"row block {sh.row_block.shape} nnz={sh.row_block.nnz}; device {dev_name} ({cus} CUs)")
+
+    t0 = time.time()
+    dC = ctx.column_shard(sh.col_block)
+    dR = ctx.row_shard(sh.row_block)
+    n_loc, m_loc, n_tot = sh.n_block, sh.row_block.shape[0], sh.row_block.shape[1]
+    d_y = ctx.to_device(sh.y)
+    d_x = ctx.to_device(sh.x)
+    off = rank * n_loc
+    d_xloc = ctx.wrap(d_x.ptr + 8 * off, n_loc, np.float64, owner=d_x)
+    roff = rank * m_loc
+    d_yloc = ctx.wrap(d_y.ptr + 8 * roff, m_loc, np.float64, owner=d_y)
+    d_c, d_l, d_u, d_b = (ctx.to_device(v) for v in (sh.c, sh.l, sh.u, sh.b))
+    s_d, code = ctx.empty(n_loc, np.float64), ctx.empty(n_loc, np.uint8)
+    s_p, flag = ctx.empty(m_loc, np.float64), ctx.empty(m_loc, np.uint8)
+    idx_low, idx_up, idx_row = ctx.empty(n_loc, np.int64), ctx.empty(n_loc, np.int64), ctx.empty(m_loc, np.int64)
+    vb = ctx.to_device(np.full(n_loc, -1, dtype=np.int8))
+    if world > 1:
+        t_counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+        t_price = torch.zeros(24, dtype=torch.uint8, device="cuda")
+        t_gather = torch.zeros(24 * world, dtype=torch.uint8, device="cuda")
+        counts = ctx.wrap(t_counts.data_ptr(), 3, np.int64, owner=t_counts)
+        price = ctx.wrap(t_price.data_ptr(), 24, np.uint8, owner=t_price)
+    else:
+        counts = ctx.empty(3, np.int64)
+        price = ctx.empty(24, np.uint8)
+    c_low = ctx.wrap(counts.ptr, 1, np.int64, owner=counts)
+    c_up = ctx.wrap(counts.ptr + 8, 1, np.int64, owner=counts)
+    c_row = ctx.wrap(counts.ptr + 16, 1, np.int64, owner=counts)
+    ctx.sync()
+    if rank == 0:
+        log(f"[bench] upload {time.time() - t0:.1f}s")
+
+    gamma = 1e-3
+    M0, M1 = 0, 1   # marker ids are 2*step, 2*step+1 around K1
+
+    def step(i, timed):
+        if timed:
+            ctx.marker(2 * i)
+        ctx.score_columns(dC, d_y, d_c, d_xloc, d_l, d_u, gamma, s_d, code)
+        if timed:
+            ctx.marker(2 * i + 1)
+        ctx.score_rows(dR, d_x, d_b, d_yloc, gamma, s_p, flag)
+        ctx.select_indices(code, 1, idx_low, c_low)
+        ctx.select_indices(code, 2, idx_up, c_up)
+        ctx.select_indices(flag, 0xFF, idx_row, c_row)
+        ctx.price(dC, d_y, d_c, vb, 1e-6, None, price)
+        if world > 1:
+            dist.all_gather_into_tensor(t_gather, t_price)
+            dist.all_reduce(t_counts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            ctx.sync_device()
+
+    for i in range(args.warmup):
+        step(i, False)
+    fence()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    k1_ms = [ctx.marker_elapsed(2 * i, 2 * i + 1) for i in range(args.steps)]
+    k1_avg_s = float(np.mean(k1_ms)) / 1e3
+    nnz_loc = sh.col_block.nnz
+    k1_bytes = 12 * nnz_loc + 49 * n_loc + 8 * m        # K1 algorithmic bytes
+    achieved = k1_bytes / k1_avg_s / 1e9
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_loc / (elapsed / args.steps)
+
+    mn, am, bad = ctx.read_price(price)
+    cnts = counts.download()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import lp_path as L     # checker / baseline only; never on the product path
+        A = sh.row_block                    # world == 1: the whole matrix in CSR
+        reps, spent = 0, 0.0
+        ref = None
+        L.scoring_pass(A, sh.b, sh.c, sh.l, sh.u, sh.x, sh.y)     # warm-up (scipy builds the CSC view lazily)
+        while reps < 5 and (spent < args.cpu_seconds or reps == 0):
+            t1 = time.perf_counter()
+            ref = L.scoring_pass(A, sh.b, sh.c, sh.l, sh.u, sh.x, sh.y)
+            spent += time.perf_counter() - t1
+            reps += 1
+        # the timed GPU pass must agree with the CPU pass it is compared with
+        same = (np.array_equal(ref["code"], code.download()) and np.array_equal(ref["rowflag"], flag.download())
+                and [ref["fix_low"].size, ref["fix_up"].size, ref["fixed_rows"].size] == [int(v) for v in cnts])
+        if not same:
+            raise SystemExit("bench: GPU scoring pass disagrees with the CPU oracle")
+        cpu = {"value": n_loc / (spent / reps), "unit": "columns/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} full scoring passes (K1+K2+np.where x3) of the same {args.workload} workload with the "
+                         f"numpy/scipy oracle, {spent / reps * 1e3:.0f} ms each; parity with the GPU pass checked",
+               "ms_per_step": spent / reps * 1e3}
+
+    if rank == 0:
+        out = {
+            "metric": "columns_scored_per_sec", "value": value, "unit": "columns/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "rows": m, "cols_per_gpu": n_loc, "cols_total": n_tot,
+                       "nnz_per_gpu": int(nnz_loc), "step": "K1 score_columns + K2 score_rows + 3x select_indices + K10 price"
+                                                            + (" + all_gather(24B) + all_reduce(3xi64)" if world > 1 else ""),
+                       "parallelism": f"column/row blocks over {world} GPU(s)"},
+            "roofline": {"kernel": "k_score_columns", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": int(k1_bytes), "avg_kernel_ms": k1_avg_s * 1e3,
+                         "min_kernel_ms": float(np.min(k1_ms))},
+            "cpu_baseline": cpu,
+            "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),
+                       "min_rc": mn, "argmin": am, "n_violating": bad},
+            "device": dev_name,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

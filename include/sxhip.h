@@ -1,0 +1,177 @@
+/*
+ * sxhip.h -- C ABI of libsxhip.so, the MI355X (gfx950) implementation of the
+ * smart-crossover hot path: primal-dual indicator scoring of LP columns/rows,
+ * cost perturbation, the projector CG that scales it, sub-problem compaction,
+ * network flow indicators, ranking and reduced-cost pricing.
+ *
+ * The reference (wcwj0147/smart-crossover) is pure Python and has no FFI; the
+ * entry points below are what a binding for its hot-path functions would call.
+ * Each one names the reference lines it replaces (paths relative to
+ * src/smart_crossover/).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every function returns SX_OK (0) or a negative SX_ERR_* code; the text
+ *     of the last failure on the calling thread is sx_last_error().
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP
+ *     device memory on the context's device (from sx_malloc, hipMalloc or
+ *     torch.Tensor.data_ptr()).  Functions ending in _dev take device
+ *     pointers for every array argument and only enqueue work on the
+ *     context's stream (no host synchronisation, hipGraph-capturable unless
+ *     stated); functions without the suffix take host pointers, copy in and
+ *     out and return when the outputs are valid.
+ *   - all floating point data is IEEE binary64.  Index vectors are int64,
+ *     sparse inner indices int32, sparse pointers int64, flags uint8.
+ *   - the caller owns every array it passes; the library owns handles.
+ *   - a context must not be used from two threads at the same time.
+ */
+#ifndef SXHIP_H
+#define SXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_ABI_VERSION 1
+
+#define SX_OK 0
+#define SX_ERR_INVALID (-1)     /* NULL / negative size / inconsistent shapes  -> ValueError  */
+#define SX_ERR_HIP (-2)         /* HIP runtime failure                           -> RuntimeError */
+#define SX_ERR_NOMEM (-3)       /* host or device allocation failed              -> MemoryError  */
+#define SX_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve         -> NotImplementedError */
+
+/* bits of the per-column code written by sx_score_columns */
+#define SX_CODE_LOW 1u /* x - l < gamma * s_d      : fix to lower bound */
+#define SX_CODE_UP 2u  /* u - x < gamma * (-s_d)   : fix to upper bound */
+
+typedef struct sx_ctx sx_ctx;       /* device + stream + workspace */
+typedef struct sx_matrix sx_matrix; /* one sparse matrix resident in HBM, CSR and CSC */
+
+/* ------------------------------------------------------------------ library */
+int sx_abi_version(void);
+const char *sx_last_error(void);
+/* number of visible HIP devices (does not create a context) */
+int sx_device_count(int *count);
+
+/* ------------------------------------------------------------------ context */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the context create its own non-blocking stream. */
+int sx_ctx_create(int device, void *stream, sx_ctx **out);
+int sx_ctx_destroy(sx_ctx *ctx);
+int sx_ctx_sync(sx_ctx *ctx);
+/* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
+int sx_ctx_device_info(sx_ctx *ctx, char *name, size_t name_len, int *cu_count, uint64_t *hbm_bytes);
+
+/* plumbing for hosts that do not bring their own device allocator */
+int sx_malloc(sx_ctx *ctx, size_t bytes, void **dev_out);
+int sx_free(sx_ctx *ctx, void *dev);
+int sx_upload(sx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int sx_download(sx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int sx_memset(sx_ctx *ctx, void *dst_dev, int byte, size_t bytes);
+
+/* HIP-event stopwatch on the context's stream (nestable up to 8 deep) */
+int sx_timer_start(sx_ctx *ctx);
+int sx_timer_stop(sx_ctx *ctx, float *ms_out); /* synchronises on the stop event */
+/* Non-blocking markers: record HIP event number `id` (0 <= id < 4096) on the stream; later ask for
+ * the time between two recorded markers (synchronises on the later one).  Lets a benchmark time one
+ * kernel inside a loop without putting a host sync in the loop. */
+int sx_marker_record(sx_ctx *ctx, int id);
+int sx_marker_elapsed(sx_ctx *ctx, int id_from, int id_to, float *ms_out);
+/* hipDeviceSynchronize on the context's device (all streams) */
+int sx_ctx_sync_device(sx_ctx *ctx);
+
+/* ------------------------------------------------------------------ matrix */
+/* Upload an m x n matrix.  Host CSR arrays are required (the reference keeps A as scipy CSR,
+ * formats.py:18); host CSC arrays are optional -- when NULL the library derives them by a stable
+ * counting sort, which yields per-column entries in row-major walk order, the accumulation order of
+ * scipy's A.transpose() @ y (formats.py:72).  When given they must be in that order.
+ * Duplicates and unsorted inner indices are allowed (they are walked as stored). */
+int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int64_t *csr_rowptr,
+                     const int32_t *csr_col, const double *csr_val, const int64_t *csc_colptr,
+                     const int32_t *csc_row, const double *csc_val, sx_matrix **out);
+/* Single-layout matrix for shards: is_csc != 0 -> (ptr, idx, val) are colptr[n+1]/row/val and only
+ * the column kernels (sx_score_columns, sx_price) accept it; is_csc == 0 -> rowptr[m+1]/col/val and
+ * only the row kernels accept it.  A kernel that needs the missing layout returns SX_ERR_INVALID. */
+int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int is_csc,
+                            const int64_t *ptr, const int32_t *idx, const double *val,
+                            sx_matrix **out);
+int sx_matrix_destroy(sx_matrix *A);
+int sx_matrix_dims(const sx_matrix *A, int64_t *m, int64_t *n, int64_t *nnz);
+/* device addresses of the six arrays (for tests and zero-copy consumers) */
+int sx_matrix_arrays(const sx_matrix *A, const int64_t **csr_rowptr, const int32_t **csr_col,
+                     const double **csr_val, const int64_t **csc_colptr, const int32_t **csc_row,
+                     const double **csc_val);
+/* download CSR arrays of a device matrix (rowptr[m+1], col[nnz], val[nnz]) */
+int sx_matrix_download_csr(const sx_matrix *A, int64_t *rowptr, int32_t *col, double *val);
+
+/* ------------------------------------------------------------------ K1: column scoring
+ * replaces GeneralLP.get_dual_slack (formats.py:70-72) and the two np.where tests of
+ * get_perturb_problem (lp_methods/algorithms.py:99,104-105):
+ *     s_d[j]  = c[j] - sum_i a_ij * y[i]      (entries in stored CSC order, product and sum
+ *                                               rounded separately, running sum from +0.0)
+ *     code[j] = SX_CODE_LOW * (x[j]-l[j] < gamma*s_d[j])  |  SX_CODE_UP * (u[j]-x[j] < gamma*(-s_d[j]))
+ * y has m entries; c, x, l, u, s_d, code have n.  s_d or code may be NULL (output skipped). */
+int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                         const double *x, const double *l, const double *u, double gamma,
+                         double *s_d, uint8_t *code);
+int sx_score_columns(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                     const double *x, const double *l, const double *u, double gamma, double *s_d,
+                     uint8_t *code);
+
+/* ------------------------------------------------------------------ K2: row scoring
+ * replaces GeneralLP.get_primal_slack (formats.py:74-76) and the row test
+ * (lp_methods/algorithms.py:100,106):
+ *     s_p[i]  = b[i] - sum_j a_ij * x[j]      (stored CSR order, same rounding rule)
+ *     flag[i] = s_p[i] < gamma_dual * (-y[i])
+ * x has n entries; b, y, s_p, flag have m. */
+int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, const double *b,
+                      const double *y, double gamma_dual, double *s_p, uint8_t *flag);
+int sx_score_rows(sx_ctx *ctx, const sx_matrix *A, const double *x, const double *b,
+                  const double *y, double gamma_dual, double *s_p, uint8_t *flag);
+
+/* ------------------------------------------------------------------ index sets
+ * np.where(...)[0] of a flag vector (lp_methods/algorithms.py:104-106): ascending int64 positions
+ * i with (flags[i] & mask) != 0.  idx_out needs room for n entries; *count_out (device int64 for
+ * _dev, host int64 otherwise) receives how many were written. */
+int sx_select_indices_dev(sx_ctx *ctx, int64_t n, const uint8_t *flags, uint8_t mask,
+                          int64_t *idx_out, int64_t *count_out);
+int sx_select_indices(sx_ctx *ctx, int64_t n, const uint8_t *flags, uint8_t mask, int64_t *idx_out,
+                      int64_t *count_out);
+
+/* ------------------------------------------------------------------ K3: perturbed cost
+ * replaces perturb_c / get_x_perturb_val after the random direction and the scale factor are
+ * known (lp_methods/algorithms.py:130-132,139-141,148-151,196-202).  xi is the normalised
+ * direction (legacy MT19937, seed 42, U(0.9,1), divided by its 2-norm) supplied by the host.
+ *   is_feas != 0 : c_pt = c + xi
+ *   otherwise    : xr = min(x-l, u-x); free -> x; xr < 1e-6 -> 1e-6; free -> 1
+ *                  p = min(xi / xr * scale_factor / 1e-2, 1e6); free -> 0; c_pt = c + p */
+int sx_perturb_cost_dev(sx_ctx *ctx, int64_t n, const double *x, const double *l, const double *u,
+                        const double *c, const double *xi, double scale_factor, int is_feas,
+                        double *c_pt);
+int sx_perturb_cost(sx_ctx *ctx, int64_t n, const double *x, const double *l, const double *u,
+                    const double *c, const double *xi, double scale_factor, int is_feas,
+                    double *c_pt);
+
+/* ------------------------------------------------------------------ K10: pricing
+ * replaces get_reduced_cost_for_original_mcf + the reduced-cost half of
+ * check_optimality_condition (network_methods/net_manager.py:302-303,318 and :483,496):
+ *     rc[j] = c[j] - sum_i a_ij*y[i];  rc[j] = -rc[j] where vbasis[j] == -2
+ * vbasis (int8: 0 basic, -1 at lower, -2 at upper, -3 free) may be NULL (no flips); rc may be NULL.
+ * result: most negative reduced cost, its smallest column index, and the number of columns that
+ * fail rc >= -tol (NaN counts as failing). */
+typedef struct sx_price_result {
+    double min_rc;
+    int64_t argmin;
+    int64_t n_violating;
+} sx_price_result;
+int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                 const int8_t *vbasis, double tol, double *rc, sx_price_result *result_dev);
+int sx_price(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+             const int8_t *vbasis, double tol, double *rc, sx_price_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SXHIP_H */

@@ -1,0 +1,407 @@
+// Context, memory plumbing, stopwatch and matrix residency of libsxhip.so.
+#include "sx_internal.h"
+
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void sx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+SX_API int sx_abi_version(void) { return SX_ABI_VERSION; }
+SX_API const char *sx_last_error(void) { return g_err; }
+
+SX_API int sx_device_count(int *count) {
+    SX_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return SX_OK;
+}
+
+SX_API int sx_ctx_create(int device, void *stream, sx_ctx **out) {
+    SX_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    SX_HIP(hipGetDeviceCount(&ndev));
+    SX_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    sx_device_guard guard(device);
+    SX_REQUIRE(guard.ok, "cannot select device %d", device);
+    sx_ctx *ctx = new (std::nothrow) sx_ctx();
+    if (!ctx) {
+        sx_set_error("out of host memory");
+        return SX_ERR_NOMEM;
+    }
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+        ctx->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            sx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return SX_ERR_HIP;
+        }
+        ctx->owns_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return SX_OK;
+}
+
+SX_API int sx_ctx_destroy(sx_ctx *ctx) {
+    if (!ctx) return SX_OK;
+    sx_device_guard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->t_made)
+        for (int i = 0; i < 8; ++i) {
+            (void)hipEventDestroy(ctx->t0[i]);
+            (void)hipEventDestroy(ctx->t1[i]);
+        }
+    for (hipEvent_t e : ctx->markers)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SX_OK;
+}
+
+SX_API int sx_ctx_sync(sx_ctx *ctx) {
+    SX_ENTER(ctx);
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_ctx_device_info(sx_ctx *ctx, char *name, size_t name_len, int *cu_count,
+                              uint64_t *hbm_bytes) {
+    SX_ENTER(ctx);
+    hipDeviceProp_t prop;
+    SX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) {
+        snprintf(name, name_len, "%s", prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = static_cast<uint64_t>(prop.totalGlobalMem);
+    return SX_OK;
+}
+
+int sx_reserve(sx_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return SX_OK;
+    // the old block may still be in use by enqueued kernels
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) SX_HIP(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = std::max(bytes, static_cast<size_t>(1) << 20);
+    want = (want + 255) & ~static_cast<size_t>(255);
+    SX_HIP(hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return SX_OK;
+}
+
+SX_API int sx_malloc(sx_ctx *ctx, size_t bytes, void **dev_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(dev_out != nullptr, "dev_out is NULL");
+    *dev_out = nullptr;
+    if (bytes == 0) bytes = 8;
+    SX_HIP(hipMalloc(dev_out, bytes));
+    return SX_OK;
+}
+
+SX_API int sx_free(sx_ctx *ctx, void *dev) {
+    SX_ENTER(ctx);
+    if (!dev) return SX_OK;
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    SX_HIP(hipFree(dev));
+    return SX_OK;
+}
+
+SX_API int sx_upload(sx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    SX_ENTER(ctx);
+    if (bytes == 0) return SX_OK;
+    SX_REQUIRE(dst_dev && src_host, "NULL pointer in sx_upload");
+    SX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream)); // the host buffer may be reused on return
+    return SX_OK;
+}
+
+SX_API int sx_download(sx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    SX_ENTER(ctx);
+    if (bytes == 0) return SX_OK;
+    SX_REQUIRE(dst_host && src_dev, "NULL pointer in sx_download");
+    SX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_memset(sx_ctx *ctx, void *dst_dev, int byte, size_t bytes) {
+    SX_ENTER(ctx);
+    if (bytes == 0) return SX_OK;
+    SX_REQUIRE(dst_dev != nullptr, "NULL pointer in sx_memset");
+    SX_HIP(hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_timer_start(sx_ctx *ctx) {
+    SX_ENTER(ctx);
+    if (!ctx->t_made) {
+        for (int i = 0; i < 8; ++i) {
+            SX_HIP(hipEventCreate(&ctx->t0[i]));
+            SX_HIP(hipEventCreate(&ctx->t1[i]));
+        }
+        ctx->t_made = true;
+    }
+    SX_REQUIRE(ctx->t_depth < 8, "timer nesting deeper than 8");
+    SX_HIP(hipEventRecord(ctx->t0[ctx->t_depth], ctx->stream));
+    ctx->t_depth++;
+    return SX_OK;
+}
+
+SX_API int sx_timer_stop(sx_ctx *ctx, float *ms_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(ctx->t_depth > 0, "sx_timer_stop without sx_timer_start");
+    ctx->t_depth--;
+    int d = ctx->t_depth;
+    SX_HIP(hipEventRecord(ctx->t1[d], ctx->stream));
+    SX_HIP(hipEventSynchronize(ctx->t1[d]));
+    float ms = 0.f;
+    SX_HIP(hipEventElapsedTime(&ms, ctx->t0[d], ctx->t1[d]));
+    if (ms_out) *ms_out = ms;
+    return SX_OK;
+}
+
+SX_API int sx_marker_record(sx_ctx *ctx, int id) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(id >= 0 && id < 4096, "marker id %d out of range [0,4096)", id);
+    if (ctx->markers.size() <= static_cast<size_t>(id)) ctx->markers.resize(id + 1, nullptr);
+    if (!ctx->markers[id]) SX_HIP(hipEventCreate(&ctx->markers[id]));
+    SX_HIP(hipEventRecord(ctx->markers[id], ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_marker_elapsed(sx_ctx *ctx, int id_from, int id_to, float *ms_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(ms_out != nullptr, "ms_out is NULL");
+    const int hi = static_cast<int>(ctx->markers.size());
+    SX_REQUIRE(id_from >= 0 && id_from < hi && id_to >= 0 && id_to < hi && ctx->markers[id_from] &&
+                   ctx->markers[id_to],
+               "marker %d or %d was never recorded", id_from, id_to);
+    SX_HIP(hipEventSynchronize(ctx->markers[id_to]));
+    SX_HIP(hipEventElapsedTime(ms_out, ctx->markers[id_from], ctx->markers[id_to]));
+    return SX_OK;
+}
+
+SX_API int sx_ctx_sync_device(sx_ctx *ctx) {
+    SX_ENTER(ctx);
+    SX_HIP(hipDeviceSynchronize());
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------ matrix
+template <class T>
+static int upload_padded(sx_ctx *ctx, const T *host, int64_t count, T **dev_out) {
+    *dev_out = nullptr;
+    size_t bytes = static_cast<size_t>(count + SX_PAD) * sizeof(T);
+    T *d = nullptr;
+    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    *dev_out = d;
+    SX_HIP(hipMemsetAsync(d + count, 0, SX_PAD * sizeof(T), ctx->stream));
+    if (count)
+        SX_HIP(hipMemcpyAsync(d, host, static_cast<size_t>(count) * sizeof(T), hipMemcpyHostToDevice,
+                              ctx->stream));
+    return SX_OK;
+}
+
+static int check_ptr(const int64_t *ptr, int64_t nseg, int64_t nnz, const char *what) {
+    SX_REQUIRE(ptr[0] == 0, "%s[0] must be 0", what);
+    for (int64_t s = 0; s < nseg; ++s)
+        SX_REQUIRE(ptr[s + 1] >= ptr[s], "%s is not non-decreasing at %lld", what, (long long)s);
+    SX_REQUIRE(ptr[nseg] == nnz, "%s[last] = %lld but nnz = %lld", what, (long long)ptr[nseg],
+               (long long)nnz);
+    return SX_OK;
+}
+
+static int check_idx(const int32_t *idx, int64_t nnz, int64_t bound, const char *what) {
+    for (int64_t k = 0; k < nnz; ++k)
+        SX_REQUIRE(idx[k] >= 0 && idx[k] < bound, "%s[%lld] = %d out of range [0,%lld)", what,
+                   (long long)k, idx[k], (long long)bound);
+    return SX_OK;
+}
+
+SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
+                            const int64_t *csr_rowptr, const int32_t *csr_col,
+                            const double *csr_val, const int64_t *csc_colptr,
+                            const int32_t *csc_row, const double *csc_val, sx_matrix **out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    SX_REQUIRE(m >= 0 && n >= 0 && nnz >= 0, "negative dimension");
+    SX_REQUIRE(m < INT32_MAX && n < INT32_MAX, "dimension exceeds int32 inner-index range");
+    SX_REQUIRE(csr_rowptr != nullptr, "csr_rowptr is NULL");
+    SX_REQUIRE(nnz == 0 || (csr_col && csr_val), "csr_col/csr_val is NULL");
+    SX_TRY(check_ptr(csr_rowptr, m, nnz, "csr_rowptr"));
+    SX_TRY(check_idx(csr_col, nnz, n, "csr_col"));
+    const bool have_csc = csc_colptr != nullptr;
+    if (have_csc) {
+        SX_REQUIRE(nnz == 0 || (csc_row && csc_val), "csc_row/csc_val is NULL");
+        SX_TRY(check_ptr(csc_colptr, n, nnz, "csc_colptr"));
+        SX_TRY(check_idx(csc_row, nnz, m, "csc_row"));
+    }
+    std::vector<int64_t> cptr;
+    std::vector<int32_t> crow;
+    std::vector<double> cval;
+    if (!have_csc) {
+        // stable counting sort by column == row-major walk order inside every column
+        try {
+            cptr.assign(static_cast<size_t>(n) + 1, 0);
+            crow.resize(static_cast<size_t>(nnz));
+            cval.resize(static_cast<size_t>(nnz));
+        } catch (const std::bad_alloc &) {
+            sx_set_error("out of host memory building CSC");
+            return SX_ERR_NOMEM;
+        }
+        for (int64_t k = 0; k < nnz; ++k) cptr[static_cast<size_t>(csr_col[k]) + 1]++;
+        for (int64_t j = 0; j < n; ++j) cptr[j + 1] += cptr[j];
+        std::vector<int64_t> next(cptr.begin(), cptr.end() - 1);
+        for (int64_t i = 0; i < m; ++i)
+            for (int64_t k = csr_rowptr[i]; k < csr_rowptr[i + 1]; ++k) {
+                int64_t dst = next[csr_col[k]]++;
+                crow[dst] = static_cast<int32_t>(i);
+                cval[dst] = csr_val[k];
+            }
+        csc_colptr = cptr.data();
+        csc_row = crow.data();
+        csc_val = cval.data();
+    }
+    sx_matrix *A = new (std::nothrow) sx_matrix();
+    if (!A) {
+        sx_set_error("out of host memory");
+        return SX_ERR_NOMEM;
+    }
+    A->ctx = ctx;
+    A->m = m;
+    A->n = n;
+    A->nnz = nnz;
+    int rc = SX_OK;
+    if ((rc = upload_padded(ctx, csr_rowptr, m + 1, &A->csr_ptr)) == SX_OK &&
+        (rc = upload_padded(ctx, csr_col, nnz, &A->csr_idx)) == SX_OK &&
+        (rc = upload_padded(ctx, csr_val, nnz, &A->csr_val)) == SX_OK &&
+        (rc = upload_padded(ctx, csc_colptr, n + 1, &A->csc_ptr)) == SX_OK &&
+        (rc = upload_padded(ctx, csc_row, nnz, &A->csc_idx)) == SX_OK &&
+        (rc = upload_padded(ctx, csc_val, nnz, &A->csc_val)) == SX_OK) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sx_set_error("stream sync failed after matrix upload");
+            rc = SX_ERR_HIP;
+        }
+    }
+    if (rc != SX_OK) {
+        sx_matrix_destroy(A);
+        return rc;
+    }
+    *out = A;
+    return SX_OK;
+}
+
+SX_API int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int is_csc,
+                                   const int64_t *ptr, const int32_t *idx, const double *val,
+                                   sx_matrix **out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    SX_REQUIRE(m >= 0 && n >= 0 && nnz >= 0, "negative dimension");
+    SX_REQUIRE(m < INT32_MAX && n < INT32_MAX, "dimension exceeds int32 inner-index range");
+    SX_REQUIRE(ptr != nullptr, "ptr is NULL");
+    SX_REQUIRE(nnz == 0 || (idx && val), "idx/val is NULL");
+    const int64_t nseg = is_csc ? n : m, bound = is_csc ? m : n;
+    SX_TRY(check_ptr(ptr, nseg, nnz, is_csc ? "colptr" : "rowptr"));
+    SX_TRY(check_idx(idx, nnz, bound, is_csc ? "row index" : "column index"));
+    sx_matrix *A = new (std::nothrow) sx_matrix();
+    if (!A) {
+        sx_set_error("out of host memory");
+        return SX_ERR_NOMEM;
+    }
+    A->ctx = ctx;
+    A->m = m;
+    A->n = n;
+    A->nnz = nnz;
+    int rc;
+    if (is_csc) {
+        (rc = upload_padded(ctx, ptr, n + 1, &A->csc_ptr)) == SX_OK &&
+            (rc = upload_padded(ctx, idx, nnz, &A->csc_idx)) == SX_OK &&
+            (rc = upload_padded(ctx, val, nnz, &A->csc_val));
+    } else {
+        (rc = upload_padded(ctx, ptr, m + 1, &A->csr_ptr)) == SX_OK &&
+            (rc = upload_padded(ctx, idx, nnz, &A->csr_idx)) == SX_OK &&
+            (rc = upload_padded(ctx, val, nnz, &A->csr_val));
+    }
+    if (rc == SX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        sx_set_error("stream sync failed after matrix upload");
+        rc = SX_ERR_HIP;
+    }
+    if (rc != SX_OK) {
+        sx_matrix_destroy(A);
+        return rc;
+    }
+    *out = A;
+    return SX_OK;
+}
+
+SX_API int sx_matrix_destroy(sx_matrix *A) {
+    if (!A) return SX_OK;
+    sx_device_guard guard(A->ctx->device);
+    (void)hipStreamSynchronize(A->ctx->stream);
+    void *ptrs[6] = {A->csr_ptr, A->csr_idx, A->csr_val, A->csc_ptr, A->csc_idx, A->csc_val};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete A;
+    return SX_OK;
+}
+
+SX_API int sx_matrix_dims(const sx_matrix *A, int64_t *m, int64_t *n, int64_t *nnz) {
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    if (m) *m = A->m;
+    if (n) *n = A->n;
+    if (nnz) *nnz = A->nnz;
+    return SX_OK;
+}
+
+SX_API int sx_matrix_arrays(const sx_matrix *A, const int64_t **csr_rowptr, const int32_t **csr_col,
+                            const double **csr_val, const int64_t **csc_colptr,
+                            const int32_t **csc_row, const double **csc_val) {
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    if (csr_rowptr) *csr_rowptr = A->csr_ptr;
+    if (csr_col) *csr_col = A->csr_idx;
+    if (csr_val) *csr_val = A->csr_val;
+    if (csc_colptr) *csc_colptr = A->csc_ptr;
+    if (csc_row) *csc_row = A->csc_idx;
+    if (csc_val) *csc_val = A->csc_val;
+    return SX_OK;
+}
+
+SX_API int sx_matrix_download_csr(const sx_matrix *A, int64_t *rowptr, int32_t *col, double *val) {
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(A->csr_ptr != nullptr, "matrix has no CSR layout");
+    sx_ctx *ctx = A->ctx;
+    SX_ENTER(ctx);
+    if (rowptr)
+        SX_HIP(hipMemcpyAsync(rowptr, A->csr_ptr, sizeof(int64_t) * (A->m + 1), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (col && A->nnz)
+        SX_HIP(hipMemcpyAsync(col, A->csr_idx, sizeof(int32_t) * A->nnz, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (val && A->nnz)
+        SX_HIP(hipMemcpyAsync(val, A->csr_val, sizeof(double) * A->nnz, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}

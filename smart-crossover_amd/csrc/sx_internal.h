@@ -1,0 +1,119 @@
+// Internal definitions shared by the translation units of libsxhip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "sxhip.h"
+
+#define SX_API extern "C" __attribute__((visibility("default")))
+
+void sx_set_error(const char *fmt, ...);
+
+#define SX_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            sx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,          \
+                         __LINE__);                                                                \
+            return e_ == hipErrorOutOfMemory ? SX_ERR_NOMEM : SX_ERR_HIP;                          \
+        }                                                                                          \
+    } while (0)
+
+#define SX_REQUIRE(cond, ...)                                                                      \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            sx_set_error(__VA_ARGS__);                                                             \
+            return SX_ERR_INVALID;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+#define SX_TRY(call)                                                                               \
+    do {                                                                                           \
+        int r_ = (call);                                                                           \
+        if (r_ != SX_OK) return r_;                                                                \
+    } while (0)
+
+// Every sparse array on the device is allocated with SX_PAD trailing zero entries so that the
+// 4-wide vector loads of the segment-walk kernels may run past the last entry.
+constexpr int64_t SX_PAD = 8;
+
+struct sx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // growable scratch (never grown inside an _dev call that could be under graph capture:
+    // sx_reserve is called by the host-pointer wrappers and by the first use of each size)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // timers
+    hipEvent_t t0[8];
+    hipEvent_t t1[8];
+    int t_depth = 0;
+    bool t_made = false;
+    int cu_count = 0;
+    std::vector<hipEvent_t> markers;
+};
+
+int sx_reserve(sx_ctx *ctx, size_t bytes); // ensure ctx->ws holds >= bytes
+
+struct sx_matrix {
+    sx_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0, nnz = 0;
+    int64_t *csr_ptr = nullptr;
+    int32_t *csr_idx = nullptr;
+    double *csr_val = nullptr;
+    int64_t *csc_ptr = nullptr;
+    int32_t *csc_idx = nullptr;
+    double *csc_val = nullptr;
+};
+
+// RAII guard: make the context's device current for the duration of a call.
+struct sx_device_guard {
+    int prev = -1;
+    bool ok = true;
+    explicit sx_device_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~sx_device_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+#define SX_ENTER(ctx)                                                                              \
+    SX_REQUIRE((ctx) != nullptr, "ctx is NULL");                                                   \
+    sx_device_guard guard_((ctx)->device);                                                         \
+    SX_REQUIRE(guard_.ok, "cannot select device %d", (ctx)->device)
+
+// temporary device copies of host arrays for the host-pointer wrappers
+struct sx_stage {
+    sx_ctx *ctx;
+    std::vector<void *> bufs;
+    explicit sx_stage(sx_ctx *c) : ctx(c) {}
+    ~sx_stage() {
+        for (void *p : bufs) (void)hipFree(p);
+    }
+    // allocate `bytes` on the device; copy from src when src != nullptr
+    int in(const void *src, size_t bytes, void **out) {
+        *out = nullptr;
+        if (bytes == 0) bytes = 8;
+        void *p = nullptr;
+        SX_HIP(hipMalloc(&p, bytes));
+        bufs.push_back(p);
+        if (src) SX_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        *out = p;
+        return SX_OK;
+    }
+    int out(void *dst_host, const void *src_dev, size_t bytes) {
+        if (dst_host && bytes)
+            SX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return SX_OK;
+    }
+};

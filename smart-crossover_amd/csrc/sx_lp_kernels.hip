@@ -1,0 +1,487 @@
+// LP-side kernels of the perturbation crossover (gfx950): K1 column scoring, K2 row scoring,
+// index-set selection, K3 cost perturbation, K10 pricing.  See include/sxhip.h for the contract
+// and DESIGN.md for layout / roofline notes.  Built with -ffp-contract=off: every product and
+// every sum below is a separately rounded binary64 operation.
+#include "sx_internal.h"
+#include "sx_segwalk.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int CHUNK1 = 4096; // 32 KiB of staged products per workgroup -> 5 workgroups / CU
+
+struct StageDot {
+    const double *__restrict__ vec;
+    __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[1]) const {
+        o[0] = v * vec[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------- K1
+__global__ __launch_bounds__(SX_WG) void k_score_columns(
+    const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+    const double *__restrict__ val, int64_t n, const double *__restrict__ y,
+    const double *__restrict__ c, const double *__restrict__ x, const double *__restrict__ l,
+    const double *__restrict__ u, double gamma, double *__restrict__ s_d,
+    uint8_t *__restrict__ code) {
+    __shared__ sx_walk_lds<1, CHUNK1> lds;
+    double acc[1];
+    int64_t j;
+    bool valid;
+    sx_segwalk<1, CHUNK1>(colptr, rowidx, val, n, StageDot{y}, lds, j, valid, acc);
+    if (!valid) return;
+    const double sd = c[j] - acc[0];
+    if (s_d) s_d[j] = sd;
+    if (code) {
+        const double xj = x[j];
+        const bool low = (xj - l[j]) < (gamma * sd);
+        const bool up = (u[j] - xj) < (gamma * (-sd));
+        code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
+    }
+}
+
+// ------------------------------------------------------------------------------------- K2
+__global__ __launch_bounds__(SX_WG) void k_score_rows(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+    const double *__restrict__ val, int64_t m, const double *__restrict__ x,
+    const double *__restrict__ b, const double *__restrict__ y, double gamma_dual,
+    double *__restrict__ s_p, uint8_t *__restrict__ flag) {
+    __shared__ sx_walk_lds<1, CHUNK1> lds;
+    double acc[1];
+    int64_t i;
+    bool valid;
+    sx_segwalk<1, CHUNK1>(rowptr, colidx, val, m, StageDot{x}, lds, i, valid, acc);
+    if (!valid) return;
+    const double sp = b[i] - acc[0];
+    if (s_p) s_p[i] = sp;
+    if (flag) flag[i] = (sp < (gamma_dual * (-y[i]))) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------- K10
+struct PricePartial {
+    double min_rc;
+    long long argmin;
+    long long n_bad;
+};
+
+__device__ __forceinline__ void price_combine(double &v, long long &ix, double v2, long long ix2) {
+    // lexicographic (value, index); indices < 0 mark "no candidate"
+    if (ix2 >= 0 && (ix < 0 || v2 < v || (v2 == v && ix2 < ix))) {
+        v = v2;
+        ix = ix2;
+    }
+}
+
+__device__ __forceinline__ void price_block_reduce(double v, long long ix, long long bad,
+                                                   PricePartial *out_slot) {
+    __shared__ double sv[SX_WG / 64];
+    __shared__ long long si[SX_WG / 64];
+    __shared__ long long sb[SX_WG / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double v2 = __shfl_down(v, o, 64);
+        long long i2 = __shfl_down(ix, o, 64);
+        price_combine(v, ix, v2, i2);
+        bad += __shfl_down(bad, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wave] = v;
+        si[wave] = ix;
+        sb[wave] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SX_WG / 64; ++w) {
+            price_combine(v, ix, sv[w], si[w]);
+            bad += sb[w];
+        }
+        out_slot->min_rc = v;
+        out_slot->argmin = ix;
+        out_slot->n_bad = bad;
+    }
+}
+
+__global__ __launch_bounds__(SX_WG) void k_price(
+    const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+    const double *__restrict__ val, int64_t n, const double *__restrict__ y,
+    const double *__restrict__ c, const int8_t *__restrict__ vbasis, double tol,
+    double *__restrict__ rc_out, PricePartial *__restrict__ partial) {
+    __shared__ sx_walk_lds<1, CHUNK1> lds;
+    double acc[1];
+    int64_t j;
+    bool valid;
+    sx_segwalk<1, CHUNK1>(colptr, rowidx, val, n, StageDot{y}, lds, j, valid, acc);
+    double v = 0.0;
+    long long ix = -1, bad = 0;
+    if (valid) {
+        double rc = c[j] - acc[0];
+        if (vbasis && vbasis[j] == -2) rc = -rc;
+        if (rc_out) rc_out[j] = rc;
+        bad = (rc >= -tol) ? 0 : 1;
+        if (rc == rc) { // NaN never becomes the minimum
+            v = rc;
+            ix = j;
+        }
+    }
+    price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
+}
+
+__global__ __launch_bounds__(SX_WG) void k_price_final(const PricePartial *__restrict__ partial,
+                                                       int64_t nblocks, sx_price_result *out) {
+    double v = 0.0;
+    long long ix = -1, bad = 0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += SX_WG) {
+        price_combine(v, ix, partial[b].min_rc, partial[b].argmin);
+        bad += partial[b].n_bad;
+    }
+    __shared__ PricePartial one;
+    price_block_reduce(v, ix, bad, &one);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->min_rc = (one.argmin >= 0) ? one.min_rc : NAN;
+        out->argmin = one.argmin;
+        out->n_violating = one.n_bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------- select
+constexpr int SEL_PER_THREAD = 16;
+constexpr int SEL_TILE = SX_WG * SEL_PER_THREAD; // 4096 flags per workgroup
+
+__device__ __forceinline__ uint32_t sel_load_mask(const uint8_t *__restrict__ flags, int64_t n,
+                                                  int64_t first, uint8_t mask) {
+    // bit t of the result <=> (flags[first+t] & mask) != 0, t in [0,16)
+    uint32_t bits = 0;
+    if (first + SEL_PER_THREAD <= n) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(flags + first);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if ((w[k] >> (8 * b)) & mask) bits |= 1u << (4 * k + b);
+    } else {
+        for (int t = 0; t < SEL_PER_THREAD; ++t)
+            if (first + t < n && (flags[first + t] & mask)) bits |= 1u << t;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(SX_WG) void k_select_count(const uint8_t *__restrict__ flags,
+                                                        int64_t n, uint8_t mask,
+                                                        int64_t *__restrict__ block_count) {
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * SEL_TILE +
+                          static_cast<int64_t>(threadIdx.x) * SEL_PER_THREAD;
+    long long cnt = (first < n) ? __popc(sel_load_mask(flags, n, first, mask)) : 0;
+    cnt = sx_wave_sum(cnt);
+    __shared__ long long s[SX_WG / 64];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of block_count in place (single workgroup), total -> *count_out
+__global__ __launch_bounds__(SX_WG) void k_select_scan(int64_t *__restrict__ block_count,
+                                                       int64_t nblocks,
+                                                       int64_t *__restrict__ count_out) {
+    __shared__ long long s[SX_WG];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nblocks; b0 += SX_WG) {
+        const int64_t b = b0 + threadIdx.x;
+        const long long mine = (b < nblocks) ? block_count[b] : 0;
+        s[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < SX_WG; o <<= 1) { // Hillis-Steele inclusive scan
+            long long add = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const long long incl = s[threadIdx.x];
+        if (b < nblocks) block_count[b] = carry + incl - mine;
+        __syncthreads();
+        if (threadIdx.x == SX_WG - 1) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = carry;
+}
+
+__global__ __launch_bounds__(SX_WG) void k_select_write(const uint8_t *__restrict__ flags,
+                                                        int64_t n, uint8_t mask,
+                                                        const int64_t *__restrict__ block_off,
+                                                        int64_t *__restrict__ idx_out) {
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * SEL_TILE +
+                          static_cast<int64_t>(threadIdx.x) * SEL_PER_THREAD;
+    uint32_t bits = (first < n) ? sel_load_mask(flags, n, first, mask) : 0u;
+    const int mine = __popc(bits);
+    // exclusive prefix of `mine` across the workgroup: wave scan + wave offsets
+    int incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __shared__ int wsum[SX_WG / 64];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int64_t dst = block_off[blockIdx.x] + woff + incl - mine;
+    while (bits) {
+        const int t = __ffs(bits) - 1;
+        bits &= bits - 1;
+        idx_out[dst++] = first + t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- K3
+__device__ __forceinline__ double np_minimum(double a, double b) {
+    return (a < b || a != a) ? a : b; // numpy.minimum: NaN wins
+}
+
+__global__ __launch_bounds__(SX_WG) void k_perturb_cost(int64_t n, const double *__restrict__ x,
+                                                        const double *__restrict__ l,
+                                                        const double *__restrict__ u,
+                                                        const double *__restrict__ c,
+                                                        const double *__restrict__ xi,
+                                                        double scale_factor, int is_feas,
+                                                        double *__restrict__ c_pt) {
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double cj = c[j], xij = xi[j];
+        if (is_feas) {
+            c_pt[j] = cj + xij;
+            continue;
+        }
+        const double xj = x[j], lj = l[j], uj = u[j];
+        const bool is_free = (lj == -INFINITY) && (uj == INFINITY);
+        double xr = np_minimum(xj - lj, uj - xj);
+        if (is_free) xr = xj;
+        if (xr < 1e-6) xr = 1e-6;
+        if (is_free) xr = 1.0;
+        double p = np_minimum(xij / xr * scale_factor / 1e-2, 1e6);
+        if (is_free) p = 0.0;
+        c_pt[j] = cj + p;
+    }
+}
+
+inline int blocks_for(int64_t nseg) { return static_cast<int>((nseg + SX_WG - 1) / SX_WG); }
+
+} // namespace
+
+// ====================================================================================== API
+SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                                const double *x, const double *l, const double *u, double gamma,
+                                double *s_d, uint8_t *code) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(A->ctx->device == ctx->device, "matrix lives on another device");
+    SX_REQUIRE(A->csc_ptr != nullptr, "matrix has no CSC layout (row shard?)");
+    SX_REQUIRE(y && c, "y or c is NULL");
+    SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
+    if (A->n == 0) return SX_OK;
+    hipLaunchKernelGGL(k_score_columns, dim3(blocks_for(A->n)), dim3(SX_WG), 0, ctx->stream,
+                       A->csc_ptr, A->csc_idx, A->csc_val, A->n, y, c, x, l, u, gamma, s_d, code);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, const double *b,
+                             const double *y, double gamma_dual, double *s_p, uint8_t *flag) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(A->ctx->device == ctx->device, "matrix lives on another device");
+    SX_REQUIRE(A->csr_ptr != nullptr, "matrix has no CSR layout (column shard?)");
+    SX_REQUIRE(x && b, "x or b is NULL");
+    SX_REQUIRE(!flag || y, "flag requested but y is NULL");
+    if (A->m == 0) return SX_OK;
+    hipLaunchKernelGGL(k_score_rows, dim3(blocks_for(A->m)), dim3(SX_WG), 0, ctx->stream,
+                       A->csr_ptr, A->csr_idx, A->csr_val, A->m, x, b, y, gamma_dual, s_p, flag);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_select_indices_dev(sx_ctx *ctx, int64_t n, const uint8_t *flags, uint8_t mask,
+                                 int64_t *idx_out, int64_t *count_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0, "n < 0");
+    SX_REQUIRE(count_out != nullptr, "count_out is NULL");
+    if (n == 0) {
+        SX_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), ctx->stream));
+        return SX_OK;
+    }
+    SX_REQUIRE(flags && idx_out, "flags or idx_out is NULL");
+    SX_REQUIRE((reinterpret_cast<uintptr_t>(flags) & 15) == 0, "flags must be 16-byte aligned");
+    const int64_t nb = (n + SEL_TILE - 1) / SEL_TILE;
+    SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(int64_t)));
+    int64_t *bc = static_cast<int64_t *>(ctx->ws);
+    hipLaunchKernelGGL(k_select_count, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream,
+                       flags, n, mask, bc);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(SX_WG), 0, ctx->stream, bc, nb, count_out);
+    hipLaunchKernelGGL(k_select_write, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream,
+                       flags, n, mask, bc, idx_out);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_perturb_cost_dev(sx_ctx *ctx, int64_t n, const double *x, const double *l,
+                               const double *u, const double *c, const double *xi,
+                               double scale_factor, int is_feas, double *c_pt) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return SX_OK;
+    SX_REQUIRE(c && xi && c_pt, "c, xi or c_pt is NULL");
+    SX_REQUIRE(is_feas || (x && l && u), "x, l or u is NULL");
+    int64_t nb = (n + SX_WG - 1) / SX_WG;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_perturb_cost, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream,
+                       n, x, l, u, c, xi, scale_factor, is_feas, c_pt);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                        const int8_t *vbasis, double tol, double *rc, sx_price_result *result_dev) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(A->ctx->device == ctx->device, "matrix lives on another device");
+    SX_REQUIRE(A->csc_ptr != nullptr, "matrix has no CSC layout (row shard?)");
+    SX_REQUIRE(y && c && result_dev, "y, c or result is NULL");
+    const int nb = blocks_for(A->n);
+    if (nb == 0) {
+        sx_price_result empty = {NAN, -1, 0};
+        SX_HIP(hipMemcpyAsync(result_dev, &empty, sizeof(empty), hipMemcpyHostToDevice, ctx->stream));
+        SX_HIP(hipStreamSynchronize(ctx->stream));
+        return SX_OK;
+    }
+    SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(PricePartial)));
+    PricePartial *partial = static_cast<PricePartial *>(ctx->ws);
+    hipLaunchKernelGGL(k_price, dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_ptr, A->csc_idx,
+                       A->csc_val, A->n, y, c, vbasis, tol, rc, partial);
+    hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial,
+                       static_cast<int64_t>(nb), result_dev);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------ host-pointer wrappers
+SX_API int sx_score_columns(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                            const double *x, const double *l, const double *u, double gamma,
+                            double *s_d, uint8_t *code) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(y && c, "y or c is NULL");
+    SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
+    const size_t nb = sizeof(double) * A->n, mb = sizeof(double) * A->m;
+    sx_stage st(ctx);
+    void *dy, *dc, *dx = nullptr, *dl = nullptr, *du = nullptr, *dsd = nullptr, *dcode = nullptr;
+    SX_TRY(st.in(y, mb, &dy));
+    SX_TRY(st.in(c, nb, &dc));
+    if (code) {
+        SX_TRY(st.in(x, nb, &dx));
+        SX_TRY(st.in(l, nb, &dl));
+        SX_TRY(st.in(u, nb, &du));
+        SX_TRY(st.in(nullptr, A->n, &dcode));
+    }
+    if (s_d) SX_TRY(st.in(nullptr, nb, &dsd));
+    SX_TRY(sx_score_columns_dev(ctx, A, (double *)dy, (double *)dc, (double *)dx, (double *)dl,
+                                (double *)du, gamma, (double *)dsd, (uint8_t *)dcode));
+    SX_TRY(st.out(s_d, dsd, nb));
+    SX_TRY(st.out(code, dcode, A->n));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_score_rows(sx_ctx *ctx, const sx_matrix *A, const double *x, const double *b,
+                         const double *y, double gamma_dual, double *s_p, uint8_t *flag) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(x && b, "x or b is NULL");
+    SX_REQUIRE(!flag || y, "flag requested but y is NULL");
+    const size_t nb = sizeof(double) * A->n, mb = sizeof(double) * A->m;
+    sx_stage st(ctx);
+    void *dx, *db, *dy = nullptr, *dsp = nullptr, *dflag = nullptr;
+    SX_TRY(st.in(x, nb, &dx));
+    SX_TRY(st.in(b, mb, &db));
+    if (flag) {
+        SX_TRY(st.in(y, mb, &dy));
+        SX_TRY(st.in(nullptr, A->m, &dflag));
+    }
+    if (s_p) SX_TRY(st.in(nullptr, mb, &dsp));
+    SX_TRY(sx_score_rows_dev(ctx, A, (double *)dx, (double *)db, (double *)dy, gamma_dual,
+                             (double *)dsp, (uint8_t *)dflag));
+    SX_TRY(st.out(s_p, dsp, mb));
+    SX_TRY(st.out(flag, dflag, A->m));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_select_indices(sx_ctx *ctx, int64_t n, const uint8_t *flags, uint8_t mask,
+                             int64_t *idx_out, int64_t *count_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0 && count_out, "bad arguments");
+    SX_REQUIRE(n == 0 || (flags && idx_out), "flags or idx_out is NULL");
+    sx_stage st(ctx);
+    void *df, *didx, *dcount;
+    SX_TRY(st.in(flags, static_cast<size_t>(n), &df));
+    SX_TRY(st.in(nullptr, sizeof(int64_t) * static_cast<size_t>(n), &didx));
+    SX_TRY(st.in(nullptr, sizeof(int64_t), &dcount));
+    SX_TRY(sx_select_indices_dev(ctx, n, (uint8_t *)df, mask, (int64_t *)didx, (int64_t *)dcount));
+    SX_TRY(st.out(count_out, dcount, sizeof(int64_t)));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    SX_TRY(st.out(idx_out, didx, sizeof(int64_t) * static_cast<size_t>(*count_out)));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_perturb_cost(sx_ctx *ctx, int64_t n, const double *x, const double *l,
+                           const double *u, const double *c, const double *xi, double scale_factor,
+                           int is_feas, double *c_pt) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return SX_OK;
+    SX_REQUIRE(c && xi && c_pt, "c, xi or c_pt is NULL");
+    SX_REQUIRE(is_feas || (x && l && u), "x, l or u is NULL");
+    const size_t nb = sizeof(double) * static_cast<size_t>(n);
+    sx_stage st(ctx);
+    void *dx = nullptr, *dl = nullptr, *du = nullptr, *dc, *dxi, *dout;
+    if (!is_feas) {
+        SX_TRY(st.in(x, nb, &dx));
+        SX_TRY(st.in(l, nb, &dl));
+        SX_TRY(st.in(u, nb, &du));
+    }
+    SX_TRY(st.in(c, nb, &dc));
+    SX_TRY(st.in(xi, nb, &dxi));
+    SX_TRY(st.in(nullptr, nb, &dout));
+    SX_TRY(sx_perturb_cost_dev(ctx, n, (double *)dx, (double *)dl, (double *)du, (double *)dc,
+                               (double *)dxi, scale_factor, is_feas, (double *)dout));
+    SX_TRY(st.out(c_pt, dout, nb));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}
+
+SX_API int sx_price(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
+                    const int8_t *vbasis, double tol, double *rc, sx_price_result *result) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr, "matrix is NULL");
+    SX_REQUIRE(y && c && result, "y, c or result is NULL");
+    const size_t nb = sizeof(double) * A->n, mb = sizeof(double) * A->m;
+    sx_stage st(ctx);
+    void *dy, *dc, *dvb = nullptr, *drc = nullptr, *dres;
+    SX_TRY(st.in(y, mb, &dy));
+    SX_TRY(st.in(c, nb, &dc));
+    if (vbasis) SX_TRY(st.in(vbasis, A->n, &dvb));
+    if (rc) SX_TRY(st.in(nullptr, nb, &drc));
+    SX_TRY(st.in(nullptr, sizeof(sx_price_result), &dres));
+    SX_TRY(sx_price_dev(ctx, A, (double *)dy, (double *)dc, (int8_t *)dvb, tol, (double *)drc,
+                        (sx_price_result *)dres));
+    SX_TRY(st.out(rc, drc, nb));
+    SX_TRY(st.out(result, dres, sizeof(sx_price_result)));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    return SX_OK;
+}

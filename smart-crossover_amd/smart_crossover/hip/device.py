@@ -1,0 +1,287 @@
+"""Thin object layer over the C ABI: device context, device vectors, resident
+sparse matrices and one Python method per kernel entry point.
+
+Everything here only marshals pointers and sizes; all arithmetic happens in
+libsxhip.so.  Device memory comes from ``sx_malloc`` by default; a
+``DeviceArray`` can also wrap foreign device memory (``torch.Tensor.data_ptr()``)
+so that RCCL collectives issued through ``torch.distributed`` can operate on
+the same buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lib as _l
+
+
+def _ptr(a) -> Optional[int]:
+    """Raw address of a DeviceArray / numpy array / None."""
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    raise TypeError(f"expected DeviceArray, ndarray or None, got {type(a)!r}")
+
+
+class Context:
+    """One HIP device + stream + scratch space (``sx_ctx``)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _l.load()
+        h = C.c_void_p()
+        _l.check(self._lib.sx_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._timer_depth = 0
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.sx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        _l.check(self._lib.sx_ctx_sync(self.handle))
+
+    def device_info(self) -> Tuple[str, int, int]:
+        name = C.create_string_buffer(128)
+        cus = C.c_int(0)
+        hbm = C.c_uint64(0)
+        _l.check(self._lib.sx_ctx_device_info(self.handle, name, 128, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value
+
+    # -- memory -----------------------------------------------------------
+    def empty(self, n: int, dtype) -> "DeviceArray":
+        return DeviceArray(self, int(n), np.dtype(dtype))
+
+    def zeros(self, n: int, dtype) -> "DeviceArray":
+        a = self.empty(n, dtype)
+        if a.nbytes:
+            _l.check(self._lib.sx_memset(self.handle, a.ptr, 0, a.nbytes))
+        return a
+
+    def to_device(self, host: np.ndarray, dtype=None) -> "DeviceArray":
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = self.empty(host.size, host.dtype)
+        a.upload(host)
+        return a
+
+    def wrap(self, ptr: int, n: int, dtype, owner=None) -> "DeviceArray":
+        """Adopt foreign device memory (kept alive by ``owner``)."""
+        return DeviceArray(self, int(n), np.dtype(dtype), ptr=int(ptr), owner=owner)
+
+    # -- stopwatch --------------------------------------------------------
+    def timer_start(self) -> None:
+        _l.check(self._lib.sx_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        _l.check(self._lib.sx_timer_stop(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def marker(self, ident: int) -> None:
+        _l.check(self._lib.sx_marker_record(self.handle, int(ident)))
+
+    def marker_elapsed(self, a: int, b: int) -> float:
+        ms = C.c_float(0)
+        _l.check(self._lib.sx_marker_elapsed(self.handle, int(a), int(b), C.byref(ms)))
+        return float(ms.value)
+
+    def sync_device(self) -> None:
+        _l.check(self._lib.sx_ctx_sync_device(self.handle))
+
+    # -- matrices ---------------------------------------------------------
+    def matrix(self, A: sp.spmatrix, csc: Optional[sp.csc_matrix] = None) -> "DeviceMatrix":
+        return DeviceMatrix(self, A, csc)
+
+    def column_shard(self, csc: sp.csc_matrix) -> "DeviceMatrix":
+        """CSC-only resident matrix (columns of one rank); entries must be in walk order."""
+        m, n = csc.shape
+        ptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(csc.indices, dtype=np.int32)
+        val = np.ascontiguousarray(csc.data, dtype=np.float64)
+        h = C.c_void_p()
+        _l.check(self._lib.sx_matrix_create_single(self.handle, m, n, csc.nnz, 1, ptr.ctypes.data, idx.ctypes.data,
+                                                   val.ctypes.data, C.byref(h)))
+        return DeviceMatrix.from_handle(self, h)
+
+    def row_shard(self, csr: sp.csr_matrix) -> "DeviceMatrix":
+        """CSR-only resident matrix (rows of one rank)."""
+        m, n = csr.shape
+        ptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        val = np.ascontiguousarray(csr.data, dtype=np.float64)
+        h = C.c_void_p()
+        _l.check(self._lib.sx_matrix_create_single(self.handle, m, n, csr.nnz, 0, ptr.ctypes.data, idx.ctypes.data,
+                                                   val.ctypes.data, C.byref(h)))
+        return DeviceMatrix.from_handle(self, h)
+
+    # -- kernels (device pointers; asynchronous on the context's stream) ---
+    def score_columns(self, A, y, c, x, l, u, gamma, s_d=None, code=None) -> None:
+        _l.check(self._lib.sx_score_columns_dev(self.handle, A.handle, _ptr(y), _ptr(c), _ptr(x), _ptr(l), _ptr(u),
+                                                float(gamma), _ptr(s_d), _ptr(code)))
+
+    def score_rows(self, A, x, b, y, gamma_dual, s_p=None, flag=None) -> None:
+        _l.check(self._lib.sx_score_rows_dev(self.handle, A.handle, _ptr(x), _ptr(b), _ptr(y), float(gamma_dual),
+                                             _ptr(s_p), _ptr(flag)))
+
+    def select_indices(self, flags: "DeviceArray", mask: int, idx_out: "DeviceArray", count_out: "DeviceArray") -> None:
+        _l.check(self._lib.sx_select_indices_dev(self.handle, flags.size, flags.ptr, int(mask), idx_out.ptr,
+                                                 count_out.ptr))
+
+    def where(self, flags: "DeviceArray", mask: int = 0xFF) -> np.ndarray:
+        """np.where(flags & mask)[0] computed on the device, returned as a host int64 array."""
+        idx = self.empty(max(flags.size, 1), np.int64)
+        cnt = self.empty(1, np.int64)
+        self.select_indices(flags, mask, idx, cnt)
+        k = int(cnt.download()[0])
+        return idx.download(k)
+
+    def perturb_cost(self, n, x, l, u, c, xi, scale_factor, is_feas, c_pt) -> None:
+        _l.check(self._lib.sx_perturb_cost_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), _ptr(c), _ptr(xi),
+                                               float(scale_factor), int(bool(is_feas)), _ptr(c_pt)))
+
+    def price(self, A, y, c, vbasis=None, tol=1e-6, rc=None, result: Optional["DeviceArray"] = None):
+        """Enqueue pricing; returns the 24-byte device record (download with ``read_price``)."""
+        if result is None:
+            result = self.empty(C.sizeof(_l.PriceResult), np.uint8)
+        _l.check(self._lib.sx_price_dev(self.handle, A.handle, _ptr(y), _ptr(c), _ptr(vbasis), float(tol), _ptr(rc),
+                                        result.ptr))
+        return result
+
+    @staticmethod
+    def read_price(result: "DeviceArray") -> Tuple[float, int, int]:
+        raw = result.download()
+        rec = _l.PriceResult.from_buffer_copy(raw.tobytes())
+        return float(rec.min_rc), int(rec.argmin), int(rec.n_violating)
+
+
+class DeviceArray:
+    """A typed, contiguous vector in HBM."""
+
+    def __init__(self, ctx: Context, n: int, dtype: np.dtype, ptr: Optional[int] = None, owner=None):
+        self.ctx = ctx
+        self.size = n
+        self.dtype = dtype
+        self.nbytes = n * dtype.itemsize
+        self._owned = ptr is None
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            _l.check(ctx._lib.sx_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)))
+            self.ptr = p.value
+        else:
+            self.ptr = ptr
+
+    def upload(self, host: np.ndarray) -> "DeviceArray":
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError(f"size mismatch: host {host.size} vs device {self.size}")
+        if self.nbytes:
+            _l.check(self.ctx._lib.sx_upload(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def download(self, count: Optional[int] = None) -> np.ndarray:
+        n = self.size if count is None else int(count)
+        out = np.empty(n, dtype=self.dtype)
+        if n:
+            _l.check(self.ctx._lib.sx_download(self.ctx.handle, out.ctypes.data, self.ptr, n * self.dtype.itemsize))
+        return out
+
+    def free(self) -> None:
+        if self._owned and self.ptr and getattr(self.ctx, "handle", None):
+            self.ctx._lib.sx_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceMatrix:
+    """A sparse matrix resident in HBM in both CSR and CSC (``sx_matrix``).
+
+    The CSC copy is derived from the CSR arrays by a stable transposition so
+    that per-column entries appear in row-major walk order (the accumulation
+    order of the reference's ``A.transpose() @ y``)."""
+
+    def __init__(self, ctx: Context, A: sp.spmatrix, csc: Optional[sp.csc_matrix] = None):
+        self.ctx = ctx
+        A = sp.csr_matrix(A)
+        if A.dtype != np.float64:
+            A = A.astype(np.float64)
+        m, n = A.shape
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        if csc is None:
+            csc = A.tocsc()          # scipy's csr_tocsc is the same stable counting sort the library uses
+        colptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
+        row = np.ascontiguousarray(csc.indices, dtype=np.int32)
+        cval = np.ascontiguousarray(csc.data, dtype=np.float64)
+        h = C.c_void_p()
+        _l.check(ctx._lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rowptr.ctypes.data, col.ctypes.data,
+                                           val.ctypes.data, colptr.ctypes.data, row.ctypes.data, cval.ctypes.data,
+                                           C.byref(h)))
+        self.handle = h
+        self.shape = (m, n)
+        self.nnz = int(A.nnz)
+
+    @classmethod
+    def from_handle(cls, ctx: Context, handle) -> "DeviceMatrix":
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.handle = handle
+        m, n, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        _l.check(ctx._lib.sx_matrix_dims(handle, C.byref(m), C.byref(n), C.byref(nnz)))
+        self.shape = (m.value, n.value)
+        self.nnz = nnz.value
+        return self
+
+    def to_scipy(self) -> sp.csr_matrix:
+        m, n = self.shape
+        rowptr = np.empty(m + 1, dtype=np.int64)
+        col = np.empty(self.nnz, dtype=np.int32)
+        val = np.empty(self.nnz, dtype=np.float64)
+        _l.check(self.ctx._lib.sx_matrix_download_csr(self.handle, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
+        return sp.csr_matrix((val, col, rowptr), shape=(m, n))
+
+    def free(self) -> None:
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.sx_matrix_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on device LOCAL_RANK (or 0).  Raises when the
+    library or a GPU is missing -- callers never get a CPU substitute."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        if _l.device_count() == 0:
+            raise _l.SxLibraryError("no HIP device visible: the smart_crossover HIP path needs an MI355X")
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

@@ -205,3 +205,110 @@ def ot(S: int, D: int, seed: int = 7, sweeps: int = 50, M: Optional[np.ndarray] 
 
 def config3(seed: int = 7) -> OTInstance:
     return ot(784, 784, seed, M=grid_cost(28))
+
+
+# --------------------------------------------------------------------------
+# config 5, sharded: one column block and one row block per rank (weak scaling)
+# --------------------------------------------------------------------------
+@dataclass
+class LPShard:
+    """What one rank holds of the global m x (world*n_block) LP."""
+    rank: int
+    world: int
+    m: int
+    n_block: int
+    col_block: sp.csc_matrix      # m x n_block, columns [rank*n_block, (rank+1)*n_block), walk order
+    row_block: sp.csr_matrix      # (m/world) x (world*n_block), rows [rank*m/world, (rank+1)*m/world)
+    y: np.ndarray                 # m            (replicated)
+    x: np.ndarray                 # world*n_block (replicated: it is the input of the crossover)
+    c: np.ndarray                 # n_block      (this rank's columns)
+    l: np.ndarray
+    u: np.ndarray
+    b: np.ndarray                 # m/world      (this rank's rows)
+
+
+def _stratum(seed: int, q: int, t: int, width: int, n_block: int):
+    rng = np.random.default_rng([seed, q, t])
+    pick = rng.integers(0, width, size=n_block, dtype=np.int32)
+    val = rng.uniform(-1.0, 1.0, size=n_block)
+    val[np.abs(val) < 1e-3] = 0.5
+    return pick, val
+
+
+def _block_vectors(seed: int, q: int, n_block: int):
+    rng = np.random.default_rng([seed, q, 1000])
+    has_up = rng.random(n_block) < 0.25
+    u = np.full(n_block, np.inf)
+    u[has_up] = rng.uniform(1.0, 10.0, int(has_up.sum()))
+    l = np.zeros(n_block)
+    basic = rng.random(n_block) < 0.1
+    x = np.full(n_block, 1e-9)
+    x[basic] = rng.uniform(0.1, 1.0, int(basic.sum()))
+    at_up = (~basic) & has_up & (rng.random(n_block) < 0.5)
+    x[at_up] = u[at_up] - 1e-9
+    s_d = np.abs(rng.standard_normal(n_block))
+    s_d[basic] = 1e-10 * rng.random(int(basic.sum()))
+    s_d[at_up] = -s_d[at_up]
+    return x, l, u, s_d
+
+
+def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_000, k: int = 8,
+             seed: int = 5) -> LPShard:
+    """Rank-local part of the config-5 style LP: every column has one entry in each of k
+    equal row strata, so row block ``rank`` (= k/world strata) can be generated without
+    generating the other ranks' entries.  world must divide k and k must divide m."""
+    if k % world or m % k:
+        raise ValueError("world must divide k and k must divide m")
+    width = m // k
+    n_total = world * n_block
+    # ---- column block (CSC, walk order = ascending stratum)
+    idx = np.empty((n_block, k), dtype=np.int32)
+    val = np.empty((n_block, k), dtype=np.float64)
+    for t in range(k):
+        pick, v = _stratum(seed, rank, t, width, n_block)
+        idx[:, t] = pick + t * width
+        val[:, t] = v
+    colptr = np.arange(n_block + 1, dtype=np.int64) * k
+    col_block = sp.csc_matrix((val.ravel(), idx.ravel(), colptr), shape=(m, n_block))
+    # ---- row block (CSR)
+    per = k // world
+    t0 = rank * per
+    m_loc = per * width
+    rows, cols, vals = [], [], []
+    for t in range(t0, t0 + per):
+        for q in range(world):
+            if q == rank:
+                pick, v = idx[:, t] - t * width, val[:, t]
+            else:
+                pick, v = _stratum(seed, q, t, width, n_block)
+            rows.append(pick + np.int32((t - t0) * width))
+            cols.append(np.arange(q * n_block, (q + 1) * n_block, dtype=np.int32))
+            vals.append(v)
+    row_block = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                              shape=(m_loc, n_total))
+    row_block.sort_indices()
+    del rows, cols, vals
+    # ---- vectors
+    rng = np.random.default_rng([seed, 7777])
+    y = rng.standard_normal(m)
+    lt = rng.random(m) < 0.5
+    y[lt] = np.where(rng.random(int(lt.sum())) < 0.5, -np.abs(y[lt]), 1e-11 * np.abs(y[lt]))
+    slack = np.zeros(m)
+    loose = lt & (y > -1e-9)
+    slack[loose] = rng.uniform(0.1, 1.0, int(loose.sum()))
+    tight = lt & ~loose
+    slack[tight] = 1e-10 * rng.random(int(tight.sum()))
+    xs = []
+    mine = None
+    for q in range(world):
+        xq, lq, uq, sdq = _block_vectors(seed, q, n_block)
+        xs.append(xq)
+        if q == rank:
+            mine = (lq, uq, sdq)
+    x = np.concatenate(xs)
+    l, u, s_d = mine
+    c = col_block.T @ y + s_d
+    r0 = rank * m_loc
+    b = row_block @ x + slack[r0:r0 + m_loc]
+    return LPShard(rank=rank, world=world, m=m, n_block=n_block, col_block=col_block, row_block=row_block, y=y, x=x,
+                   c=c, l=l, u=u, b=b)
