@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--structure", default=None, choices=["staircase", "uniform"],
+                    help="row structure of the synthetic LP (default: staircase = netlib-style for c5, uniform for c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
@@ -85,9 +87,11 @@ def main():
 
     m, n_block, k, desc = WORKLOADS[args.workload]
     t0 = time.time()
+    structure = args.structure or ("staircase" if args.workload == "c5" else "uniform")
     if m % k or k % world:
         raise SystemExit(f"workload {args.workload}: world={world} must divide nnz/col={k}")
-    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5)
+    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5, structure=structure)
+    desc = f"{desc}; row structure: {structure}"
     if rank == 0:
         log(f"[bench] generated shard in {time.time() - t0:.1f}s: col block {sh.col_block.shape} nnz={sh.col_block.nnz}, "
             f"row block {sh.row_block.shape} nnz={sh.row_block.nnz}; device {dev_name} ({cus} CUs)")

@@ -76,6 +76,22 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     return SX_OK;
 }
 
+SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
+    SX_REQUIRE(ctx != nullptr && key != nullptr, "ctx or key is NULL");
+    if (!strcmp(key, "xcd_swizzle")) {
+        ctx->opt_xcd_swizzle = value ? 1 : 0;
+    } else if (!strcmp(key, "nt_stream")) {
+        ctx->opt_nt_stream = value ? 1 : 0;
+    } else if (!strcmp(key, "chunk")) {
+        SX_REQUIRE(value == 2048 || value == 4096, "chunk must be 2048 or 4096");
+        ctx->opt_chunk = static_cast<int>(value);
+    } else {
+        sx_set_error("unknown option '%s'", key);
+        return SX_ERR_INVALID;
+    }
+    return SX_OK;
+}
+
 SX_API int sx_ctx_sync(sx_ctx *ctx) {
     SX_ENTER(ctx);
     SX_HIP(hipStreamSynchronize(ctx->stream));
@@ -304,6 +320,8 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
             rc = SX_ERR_HIP;
         }
     }
+    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles);
+    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles);
     if (rc != SX_OK) {
         sx_matrix_destroy(A);
         return rc;
@@ -348,6 +366,9 @@ SX_API int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nn
         sx_set_error("stream sync failed after matrix upload");
         rc = SX_ERR_HIP;
     }
+    if (rc == SX_OK)
+        rc = is_csc ? sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles)
+                    : sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles);
     if (rc != SX_OK) {
         sx_matrix_destroy(A);
         return rc;
@@ -360,7 +381,8 @@ SX_API int sx_matrix_destroy(sx_matrix *A) {
     if (!A) return SX_OK;
     sx_device_guard guard(A->ctx->device);
     (void)hipStreamSynchronize(A->ctx->stream);
-    void *ptrs[6] = {A->csr_ptr, A->csr_idx, A->csr_val, A->csc_ptr, A->csc_idx, A->csc_val};
+    void *ptrs[8] = {A->csr_ptr, A->csr_idx, A->csr_val,   A->csc_ptr,
+                     A->csc_idx, A->csc_val, A->csr_tiles, A->csc_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete A;

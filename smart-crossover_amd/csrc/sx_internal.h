@@ -59,6 +59,10 @@ struct sx_ctx {
     bool t_made = false;
     int cu_count = 0;
     std::vector<hipEvent_t> markers;
+    // tuning knobs (sx_ctx_set_option); defaults are the measured best on MI355X
+    int opt_xcd_swizzle = 1; // XCD-contiguous block -> tile map
+    int opt_nt_stream = 0;   // non-temporal loads for the streamed entry arrays
+    int opt_chunk = 4096;    // staged entries per chunk (2048 or 4096)
 };
 
 int sx_reserve(sx_ctx *ctx, size_t bytes); // ensure ctx->ws holds >= bytes
@@ -72,7 +76,15 @@ struct sx_matrix {
     int64_t *csc_ptr = nullptr;
     int32_t *csc_idx = nullptr;
     double *csc_val = nullptr;
+    // tile tables (sx_tiles.hip): first segment of every tile + sentinel
+    int64_t *csr_tiles = nullptr;
+    int64_t n_csr_tiles = 0;
+    int64_t *csc_tiles = nullptr;
+    int64_t n_csc_tiles = 0;
 };
+
+int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
+                   int64_t *ntiles_out);
 
 // RAII guard: make the context's device current for the duration of a call.
 struct sx_device_guard {

@@ -9,8 +9,6 @@
 
 namespace {
 
-constexpr int CHUNK1 = 4096; // 32 KiB of staged products per workgroup -> 5 workgroups / CU
-
 struct StageDot {
     const double *__restrict__ vec;
     __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[1]) const {
@@ -19,17 +17,20 @@ struct StageDot {
 };
 
 // ------------------------------------------------------------------------------------- K1
+template <int CHUNK, bool NT>
 __global__ __launch_bounds__(SX_WG) void k_score_columns(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
-    const double *__restrict__ val, int64_t n, const double *__restrict__ y,
-    const double *__restrict__ c, const double *__restrict__ x, const double *__restrict__ l,
-    const double *__restrict__ u, double gamma, double *__restrict__ s_d,
-    uint8_t *__restrict__ code) {
-    __shared__ sx_walk_lds<1, CHUNK1> lds;
+    const double *__restrict__ val, const double *__restrict__ y, const double *__restrict__ c,
+    const double *__restrict__ x, const double *__restrict__ l, const double *__restrict__ u,
+    double gamma, double *__restrict__ s_d, uint8_t *__restrict__ code) {
+    __shared__ sx_walk_lds<1, CHUNK> lds;
+    const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
+    if (tile >= ntiles) return;
     double acc[1];
     int64_t j;
     bool valid;
-    sx_segwalk<1, CHUNK1>(colptr, rowidx, val, n, StageDot{y}, lds, j, valid, acc);
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc);
     if (!valid) return;
     const double sd = c[j] - acc[0];
     if (s_d) s_d[j] = sd;
@@ -42,16 +43,20 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
 }
 
 // ------------------------------------------------------------------------------------- K2
+template <int CHUNK, bool NT>
 __global__ __launch_bounds__(SX_WG) void k_score_rows(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-    const double *__restrict__ val, int64_t m, const double *__restrict__ x,
-    const double *__restrict__ b, const double *__restrict__ y, double gamma_dual,
-    double *__restrict__ s_p, uint8_t *__restrict__ flag) {
-    __shared__ sx_walk_lds<1, CHUNK1> lds;
+    const double *__restrict__ val, const double *__restrict__ x, const double *__restrict__ b,
+    const double *__restrict__ y, double gamma_dual, double *__restrict__ s_p,
+    uint8_t *__restrict__ flag) {
+    __shared__ sx_walk_lds<1, CHUNK> lds;
+    const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
+    if (tile >= ntiles) return;
     double acc[1];
     int64_t i;
     bool valid;
-    sx_segwalk<1, CHUNK1>(rowptr, colidx, val, m, StageDot{x}, lds, i, valid, acc);
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, rowptr, colidx, val, StageDot{x}, lds, i, valid, acc);
     if (!valid) return;
     const double sp = b[i] - acc[0];
     if (s_p) s_p[i] = sp;
@@ -103,26 +108,40 @@ __device__ __forceinline__ void price_block_reduce(double v, long long ix, long 
     }
 }
 
+// grid-stride over tiles: one partial per workgroup (at most PRICE_GRID of them)
+constexpr int PRICE_GRID = 2048;
+
+template <int CHUNK, bool NT>
 __global__ __launch_bounds__(SX_WG) void k_price(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
-    const double *__restrict__ val, int64_t n, const double *__restrict__ y,
-    const double *__restrict__ c, const int8_t *__restrict__ vbasis, double tol,
-    double *__restrict__ rc_out, PricePartial *__restrict__ partial) {
-    __shared__ sx_walk_lds<1, CHUNK1> lds;
-    double acc[1];
-    int64_t j;
-    bool valid;
-    sx_segwalk<1, CHUNK1>(colptr, rowidx, val, n, StageDot{y}, lds, j, valid, acc);
+    const double *__restrict__ val, const double *__restrict__ y, const double *__restrict__ c,
+    const int8_t *__restrict__ vbasis, double tol, double *__restrict__ rc_out,
+    PricePartial *__restrict__ partial) {
+    __shared__ sx_walk_lds<1, CHUNK> lds;
     double v = 0.0;
     long long ix = -1, bad = 0;
-    if (valid) {
-        double rc = c[j] - acc[0];
-        if (vbasis && vbasis[j] == -2) rc = -rc;
-        if (rc_out) rc_out[j] = rc;
-        bad = (rc >= -tol) ? 0 : 1;
-        if (rc == rc) { // NaN never becomes the minimum
-            v = rc;
-            ix = j;
+    // tile range and stride of this workgroup: with the XCD swizzle (gridDim.x is a multiple of 8)
+    // XCD k = blockIdx % 8 walks the contiguous range [k*per, (k+1)*per) with its gridDim/8 blocks
+    int64_t t = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
+    if (swizzle) {
+        const int64_t per = (ntiles + 7) >> 3;
+        t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        t_end = ((blockIdx.x & 7) + 1) * per;
+        if (t_end > ntiles) t_end = ntiles;
+        t_step = gridDim.x >> 3;
+    }
+    for (; t < t_end; t += t_step) {
+        double acc[1];
+        int64_t j;
+        bool valid;
+        sx_segwalk<1, CHUNK, NT>(tiles, t, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc);
+        if (valid) {
+            double rc = c[j] - acc[0];
+            if (vbasis && vbasis[j] == -2) rc = -rc;
+            if (rc_out) rc_out[j] = rc;
+            bad += (rc >= -tol) ? 0 : 1;
+            if (rc == rc) price_combine(v, ix, rc, j); // NaN never becomes the minimum
         }
     }
     price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
@@ -270,7 +289,22 @@ __global__ __launch_bounds__(SX_WG) void k_perturb_cost(int64_t n, const double 
     }
 }
 
-inline int blocks_for(int64_t nseg) { return static_cast<int>((nseg + SX_WG - 1) / SX_WG); }
+// grid of a one-tile-per-workgroup launch: with the XCD swizzle every XCD gets ceil(T/8) slots
+inline unsigned walk_grid(const sx_ctx *ctx, int64_t ntiles) {
+    if (!ctx->opt_xcd_swizzle) return static_cast<unsigned>(ntiles);
+    return static_cast<unsigned>(((ntiles + 7) >> 3) << 3);
+}
+
+#define SX_DISPATCH_VARIANT(ctx, LAUNCH)                                                           \
+    do {                                                                                           \
+        if ((ctx)->opt_chunk == 2048) {                                                            \
+            if ((ctx)->opt_nt_stream) LAUNCH(2048, true);                                          \
+            else LAUNCH(2048, false);                                                              \
+        } else {                                                                                   \
+            if ((ctx)->opt_nt_stream) LAUNCH(4096, true);                                          \
+            else LAUNCH(4096, false);                                                              \
+        }                                                                                          \
+    } while (0)
 
 } // namespace
 
@@ -285,8 +319,13 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     SX_REQUIRE(y && c, "y or c is NULL");
     SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
     if (A->n == 0) return SX_OK;
-    hipLaunchKernelGGL(k_score_columns, dim3(blocks_for(A->n)), dim3(SX_WG), 0, ctx->stream,
-                       A->csc_ptr, A->csc_idx, A->csc_val, A->n, y, c, x, l, u, gamma, s_d, code);
+    const unsigned grid = walk_grid(ctx, A->n_csc_tiles);
+#define SX_LAUNCH_K1(CH, NTV)                                                                      \
+    hipLaunchKernelGGL((k_score_columns<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,        \
+                       A->csc_tiles, A->n_csc_tiles, ctx->opt_xcd_swizzle, A->csc_ptr, A->csc_idx, \
+                       A->csc_val, y, c, x, l, u, gamma, s_d, code)
+    SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K1);
+#undef SX_LAUNCH_K1
     SX_HIP(hipGetLastError());
     return SX_OK;
 }
@@ -300,8 +339,13 @@ SX_API int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, c
     SX_REQUIRE(x && b, "x or b is NULL");
     SX_REQUIRE(!flag || y, "flag requested but y is NULL");
     if (A->m == 0) return SX_OK;
-    hipLaunchKernelGGL(k_score_rows, dim3(blocks_for(A->m)), dim3(SX_WG), 0, ctx->stream,
-                       A->csr_ptr, A->csr_idx, A->csr_val, A->m, x, b, y, gamma_dual, s_p, flag);
+    const unsigned grid = walk_grid(ctx, A->n_csr_tiles);
+#define SX_LAUNCH_K2(CH, NTV)                                                                      \
+    hipLaunchKernelGGL((k_score_rows<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,           \
+                       A->csr_tiles, A->n_csr_tiles, ctx->opt_xcd_swizzle, A->csr_ptr, A->csr_idx, \
+                       A->csr_val, x, b, y, gamma_dual, s_p, flag)
+    SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K2);
+#undef SX_LAUNCH_K2
     SX_HIP(hipGetLastError());
     return SX_OK;
 }
@@ -352,7 +396,10 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     SX_REQUIRE(A->ctx->device == ctx->device, "matrix lives on another device");
     SX_REQUIRE(A->csc_ptr != nullptr, "matrix has no CSC layout (row shard?)");
     SX_REQUIRE(y && c && result_dev, "y, c or result is NULL");
-    const int nb = blocks_for(A->n);
+    // the swizzled walk needs a grid that is a multiple of 8 (one slice per XCD)
+    const int swz = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
+    int nb = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID);
+    if (swz) nb &= ~7;
     if (nb == 0) {
         sx_price_result empty = {NAN, -1, 0};
         SX_HIP(hipMemcpyAsync(result_dev, &empty, sizeof(empty), hipMemcpyHostToDevice, ctx->stream));
@@ -361,8 +408,12 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     }
     SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(PricePartial)));
     PricePartial *partial = static_cast<PricePartial *>(ctx->ws);
-    hipLaunchKernelGGL(k_price, dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_ptr, A->csc_idx,
-                       A->csc_val, A->n, y, c, vbasis, tol, rc, partial);
+#define SX_LAUNCH_K10(CH, NTV)                                                                     \
+    hipLaunchKernelGGL((k_price<CH, NTV>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,    \
+                       A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx, A->csc_val, y, c, vbasis, tol, \
+                       rc, partial)
+    SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K10);
+#undef SX_LAUNCH_K10
     hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial,
                        static_cast<int64_t>(nb), result_dev);
     SX_HIP(hipGetLastError());

@@ -3,12 +3,16 @@
 // -- the rounding order of scipy's csc_matvec / csr_matvec, which the reference's index sets
 // depend on.
 //
-// A workgroup of 256 lanes owns 256 consecutive segments, i.e. one contiguous slice
-// [ptr[s0], ptr[s0+256]) of the entry arrays.  The slice is streamed in chunks:
+// Work is cut into *tiles*: runs of at most 256 consecutive segments holding at most about
+// SX_TILE_BUDGET entries (sx_tiles.hip builds the table once per matrix), so that a few very long
+// segments (linking rows of an LP) do not serialise inside one workgroup.  A workgroup of 256
+// lanes owns one tile, i.e. one contiguous slice [ptr[s0], ptr[s1]) of the entry arrays, and
+// streams it in chunks:
 //   stage   : all lanes read entries with 16-byte loads (4 x int32 index, 2 x 2 x double value),
 //             gather the vector operand, form the rounded products and park them in LDS;
 //             this is where the HBM traffic and the memory-level parallelism are;
-//   consume : lane t adds the products of segment s0+t, in stored order, to its running sum.
+//   consume : lane t adds the products of segment s0+t, in stored order, to its running sum
+//             (LDS reads are issued eight ahead of the dependent adds).
 // Chunks are visited in ascending order, so a segment that straddles chunks (or is longer than
 // a chunk) is still summed strictly left to right.  Compile with -ffp-contract=off.
 #pragma once
@@ -17,8 +21,9 @@
 
 #include <cstdint>
 
-constexpr int SX_WG = 256;        // lanes per workgroup = segments per workgroup
+constexpr int SX_WG = 256;          // lanes per workgroup = max segments per tile
 constexpr int SX_SWEEP = SX_WG * 4; // entries staged by one sweep of 4-wide loads
+constexpr int SX_TILE_BUDGET = 8192; // a tile is cut when its entry count would pass this
 
 template <int NACC, int CHUNK>
 struct sx_walk_lds {
@@ -26,19 +31,51 @@ struct sx_walk_lds {
     double v[NACC][CHUNK];
 };
 
+// XCD-aware block -> tile map (speed only): blocks b and b+8 share an XCD (round-robin dispatch),
+// so giving XCD k the contiguous tile range [k*T/8, (k+1)*T/8) keeps the vector operand that
+// neighbouring tiles gather from in that XCD's L2.
+__device__ __forceinline__ int64_t sx_tile_of_block(int64_t b, int64_t ntiles, int swizzle) {
+    if (!swizzle) return b;
+    const int64_t per = (ntiles + 7) >> 3;
+    const int64_t t = (b & 7) * per + (b >> 3);
+    return t; // may be >= ntiles for the last XCD's tail: caller skips
+}
+
+typedef int sx_v4i __attribute__((ext_vector_type(4)));
+typedef double sx_v2d __attribute__((ext_vector_type(2)));
+
+// 16-byte loads of the streamed arrays; NT marks them non-temporal so that the once-read stream
+// does not evict the gathered operand from the vector L1
+template <bool NT>
+__device__ __forceinline__ sx_v4i sx_ld_i4(const int32_t *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(reinterpret_cast<const sx_v4i *>(p));
+    else
+        return *reinterpret_cast<const sx_v4i *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ sx_v2d sx_ld_d2(const double *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(reinterpret_cast<const sx_v2d *>(p));
+    else
+        return *reinterpret_cast<const sx_v2d *>(p);
+}
+
 // Stage functor:  void operator()(double value, int32_t index, double (&out)[NACC]) const
-// On return acc[] holds the NACC running sums of segment `seg` (valid lanes only).
-template <int NACC, int CHUNK, class Stage>
-__device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ ptr,
+// Walks tile `tile` (segments [tiles[tile], tiles[tile+1])).  On return acc[] holds the NACC
+// running sums of segment `seg` (valid lanes only).
+template <int NACC, int CHUNK, bool NT = false, class Stage>
+__device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, int64_t tile,
+                                           const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx,
-                                           const double *__restrict__ val, int64_t nseg,
-                                           const Stage &stage, sx_walk_lds<NACC, CHUNK> &lds,
-                                           int64_t &seg, bool &valid, double (&acc)[NACC]) {
+                                           const double *__restrict__ val, const Stage &stage,
+                                           sx_walk_lds<NACC, CHUNK> &lds, int64_t &seg, bool &valid,
+                                           double (&acc)[NACC]) {
     const int tid = threadIdx.x;
-    const int64_t s0 = static_cast<int64_t>(blockIdx.x) * SX_WG;
-    const int64_t s1 = (s0 + SX_WG < nseg) ? s0 + SX_WG : nseg;
+    const int64_t s0 = tiles[tile];
+    const int64_t s1 = tiles[tile + 1];
     seg = s0 + tid;
-    valid = seg < nseg;
+    valid = seg < s1;
     const int64_t p_lo = ptr[s0];
     const int64_t p_hi = ptr[s1];
     int64_t cs = p_hi, ce = p_hi;
@@ -56,13 +93,13 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ ptr,
             const int64_t sweep0 = base + static_cast<int64_t>(r) * SX_SWEEP;
             if (sweep0 < p_hi) { // uniform across the workgroup
                 const int off = r * SX_SWEEP + tid * 4;
-                int64_t e = base + off;
+                const int64_t e = base + off;
                 // lanes past the slice re-read its first quad (cached) instead of branching;
                 // their LDS slots are never consumed
                 const int64_t ee = (e < p_hi) ? e : base;
-                const int4 i4 = *reinterpret_cast<const int4 *>(idx + ee);
-                const double2 v01 = *reinterpret_cast<const double2 *>(val + ee);
-                const double2 v23 = *reinterpret_cast<const double2 *>(val + ee + 2);
+                const sx_v4i i4 = sx_ld_i4<NT>(idx + ee);
+                const sx_v2d v01 = sx_ld_d2<NT>(val + ee);
+                const sx_v2d v23 = sx_ld_d2<NT>(val + ee + 2);
                 double o0[NACC], o1[NACC], o2[NACC], o3[NACC];
                 stage(v01.x, i4.x, o0);
                 stage(v01.y, i4.y, o1);
@@ -77,11 +114,23 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ ptr,
             }
         }
         __syncthreads();
-        // ---- consume: strictly sequential per lane
+        // ---- consume: strictly sequential per lane, reads batched ahead of the adds
         const int64_t k0 = cs > base ? cs : base;
         const int64_t k1 = ce < base + CHUNK ? ce : base + CHUNK;
-        for (int64_t k = k0; k < k1; ++k) {
-            const int o = static_cast<int>(k - base);
+        int o = static_cast<int>(k0 - base);
+        int left = (k1 > k0) ? static_cast<int>(k1 - k0) : 0;
+        for (; left >= 8; left -= 8, o += 8) {
+            double t[NACC][8];
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[a][q] = lds.v[a][o + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = acc[a] + t[a][q];
+        }
+        for (; left > 0; --left, ++o) {
 #pragma unroll
             for (int a = 0; a < NACC; ++a) acc[a] = acc[a] + lds.v[a][o];
         }
@@ -90,15 +139,6 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ ptr,
 }
 
 // ------------------------------------------------------------------ small reductions
-__device__ __forceinline__ double sx_wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double w = __shfl_down(v, o, 64);
-        v = (w < v) ? w : v;
-    }
-    return v;
-}
-
 __device__ __forceinline__ long long sx_wave_sum(long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

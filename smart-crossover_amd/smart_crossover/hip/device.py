@@ -55,6 +55,9 @@ class Context:
     def sync(self) -> None:
         _l.check(self._lib.sx_ctx_sync(self.handle))
 
+    def set_option(self, key: str, value: int) -> None:
+        _l.check(self._lib.sx_ctx_set_option(self.handle, key.encode(), int(value)))
+
     def device_info(self) -> Tuple[str, int, int]:
         name = C.create_string_buffer(128)
         cus = C.c_int(0)

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "sx_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
     "sx_ctx_destroy": (_int, [_vp]),
     "sx_ctx_sync": (_int, [_vp]),
+    "sx_ctx_set_option": (_int, [_vp, C.c_char_p, _i64]),
     "sx_ctx_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(C.c_uint64)]),
     "sx_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "sx_free": (_int, [_vp, _vp]),

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of the scoring kernels under different tuning knobs (one process,
+same data, several rounds; median and min per variant).
+
+    python tools/kbench.py [--workload c5|c2] [--structure staircase|uniform] [--rounds 7]
+"""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
+
+import workloads  # noqa: E402
+from smart_crossover.hip import Context  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c5")
+    ap.add_argument("--structure", default="staircase")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    m, nb, k = (1_000_000, 10_000_000, 8) if args.workload == "c5" else (20_000, 100_000, 20)
+    structure = args.structure if args.workload == "c5" else "uniform"
+    sh = workloads.lp_shard(0, 1, m=m, n_block=nb, k=k, structure=structure)
+    ctx = Context(0)
+    dC, dR = ctx.column_shard(sh.col_block), ctx.row_shard(sh.row_block)
+    d = {kk: ctx.to_device(getattr(sh, kk)) for kk in ("y", "x", "c", "l", "u", "b")}
+    s_d, code = ctx.empty(nb, np.float64), ctx.empty(nb, np.uint8)
+    s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
+    k1_bytes = 12 * sh.col_block.nnz + 49 * nb + 8 * m
+    k2_bytes = 12 * sh.row_block.nnz + 8 * nb + 33 * m
+
+    variants = list(itertools.product((0, 1), (0, 1), (4096, 2048)))   # swizzle, nt, chunk
+    res = {v: {"k1": [], "k2": []} for v in variants}
+    ref = None
+    for rnd in range(args.rounds):
+        for v in variants:
+            ctx.set_option("xcd_swizzle", v[0])
+            ctx.set_option("nt_stream", v[1])
+            ctx.set_option("chunk", v[2])
+            ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)   # warm
+            ctx.marker(0)
+            for _ in range(args.reps):
+                ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)
+            ctx.marker(1)
+            for _ in range(args.reps):
+                ctx.score_rows(dR, d["x"], d["b"], d["y"], 1e-3, s_p, flag)
+            ctx.marker(2)
+            res[v]["k1"].append(ctx.marker_elapsed(0, 1) / args.reps)
+            res[v]["k2"].append(ctx.marker_elapsed(1, 2) / args.reps)
+            if rnd == 0:   # knobs must never change results
+                got = (s_d.download().tobytes(), code.download().tobytes(), s_p.download().tobytes(), flag.download().tobytes())
+                if ref is None:
+                    ref = got
+                assert got == ref, f"variant {v} changed the results"
+    print(f"workload {args.workload}/{structure}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
+    print("swz nt chunk |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med)")
+    for v in variants:
+        a, b = np.array(res[v]["k1"]), np.array(res[v]["k2"])
+        print(f" {v[0]}  {v[1]}  {v[2]:4d} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
+              f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f}")
+
+
+if __name__ == "__main__":
+    main()

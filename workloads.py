@@ -252,16 +252,11 @@ def _block_vectors(seed: int, q: int, n_block: int):
     return x, l, u, s_d
 
 
-def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_000, k: int = 8,
-             seed: int = 5) -> LPShard:
-    """Rank-local part of the config-5 style LP: every column has one entry in each of k
-    equal row strata, so row block ``rank`` (= k/world strata) can be generated without
-    generating the other ranks' entries.  world must divide k and k must divide m."""
-    if k % world or m % k:
-        raise ValueError("world must divide k and k must divide m")
+def _uniform_blocks(rank, world, m, n_block, k, seed):
+    """Column block + row block when every column has one entry in each of k equal row strata
+    (rows uniformly random inside a stratum): no locality at all, the worst case for the gathers."""
     width = m // k
     n_total = world * n_block
-    # ---- column block (CSC, walk order = ascending stratum)
     idx = np.empty((n_block, k), dtype=np.int32)
     val = np.empty((n_block, k), dtype=np.float64)
     for t in range(k):
@@ -270,7 +265,6 @@ def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_00
         val[:, t] = v
     colptr = np.arange(n_block + 1, dtype=np.int64) * k
     col_block = sp.csc_matrix((val.ravel(), idx.ravel(), colptr), shape=(m, n_block))
-    # ---- row block (CSR)
     per = k // world
     t0 = rank * per
     m_loc = per * width
@@ -287,7 +281,108 @@ def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_00
     row_block = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
                               shape=(m_loc, n_total))
     row_block.sort_indices()
-    del rows, cols, vals
+    return col_block, row_block
+
+
+STAIR_REGIONS = 8     # row regions; every rank owns 8/world of them
+
+
+def _stair_geometry(m: int, window: int):
+    mr = m // STAIR_REGIONS                   # rows per region
+    nl = max(1, mr // 100)                    # linking rows at the head of each region (1 %)
+    ms = mr - nl                              # stage rows of the region
+    W = max(6, min(window, ms // 4))
+    return mr, nl, ms, W
+
+
+def _stair_linking(seed: int, q: int, n_block: int, nl: int):
+    """Slot 7 of block q: one linking entry per column (region, row inside the region's linking rows, value)."""
+    rng = np.random.default_rng([seed, q, 7])
+    region = rng.integers(0, STAIR_REGIONS, size=n_block, dtype=np.int32)
+    off = rng.integers(0, nl, size=n_block, dtype=np.int32)
+    val = rng.uniform(-1.0, 1.0, size=n_block)
+    val[np.abs(val) < 1e-3] = 0.5
+    return region, off, val
+
+
+def _staircase_blocks(rank, world, m, n_block, k, seed, window):
+    """Netlib-style structure (staircase / block-angular with linking rows), 8 entries per column:
+    six in a window of W stage rows at the column's home position, one in the following window
+    (the coupling to the next stage) and one in a linking row (1 % of the rows, shared by all
+    stages).  Home positions grow with the column index, so neighbouring columns touch
+    neighbouring rows, as in multi-period netlib models."""
+    if k != 8:
+        raise ValueError("the staircase generator places exactly 8 entries per column")
+    G = STAIR_REGIONS // world                # regions owned by this rank
+    if n_block % G:
+        raise ValueError("n_block must be divisible by 8/world")
+    mr, nl, ms, W = _stair_geometry(m, window)
+    ws = W // 6
+    per_region = n_block // G
+    j = np.arange(n_block, dtype=np.int64)
+    g_loc = (j // per_region).astype(np.int32)                  # region (local) of the column's stage rows
+    home = ((j % per_region) * (ms - 2 * W) // per_region).astype(np.int32)
+    g_glob = g_loc + rank * G
+    base = g_glob * mr + nl + home                               # first row of the column's window
+    idx = np.empty((n_block, 8), dtype=np.int32)
+    val = np.empty((n_block, 8), dtype=np.float64)
+    for t in range(7):
+        rng = np.random.default_rng([seed, rank, t])
+        if t < 6:
+            off = t * ws + rng.integers(0, ws, size=n_block, dtype=np.int32)
+        else:
+            off = W + rng.integers(0, W, size=n_block, dtype=np.int32)
+        v = rng.uniform(-1.0, 1.0, size=n_block)
+        v[np.abs(v) < 1e-3] = 0.5
+        idx[:, t] = base + off
+        val[:, t] = v
+    region, off7, v7 = _stair_linking(seed, rank, n_block, nl)
+    idx[:, 7] = region * mr + off7
+    val[:, 7] = v7
+    # ascending rows inside every column: the linking entry goes first when its region is not
+    # after the column's own region, last otherwise
+    first = region <= g_glob
+    order = np.where(first[:, None], np.array([7, 0, 1, 2, 3, 4, 5, 6]), np.arange(8))
+    idx_sorted = np.take_along_axis(idx, order, axis=1)
+    val_sorted = np.take_along_axis(val, order, axis=1)
+    colptr = np.arange(n_block + 1, dtype=np.int64) * 8
+    col_block = sp.csc_matrix((val_sorted.ravel(), idx_sorted.ravel(), colptr), shape=(m, n_block))
+    # ---- row block: stage entries of my own columns + linking entries of every block that land in my regions
+    r0 = rank * G * mr
+    m_loc = G * mr
+    n_total = world * n_block
+    rows = [(idx[:, :7] - r0).ravel()]
+    cols = [np.repeat(np.arange(rank * n_block, (rank + 1) * n_block, dtype=np.int32), 7)]
+    vals = [val[:, :7].ravel()]
+    for q in range(world):
+        rg, of, vv = (region, off7, v7) if q == rank else _stair_linking(seed, q, n_block, nl)
+        mine = (rg >= rank * G) & (rg < (rank + 1) * G)
+        rows.append((rg[mine] * mr + of[mine] - r0).astype(np.int32))
+        cols.append((np.flatnonzero(mine) + q * n_block).astype(np.int32))
+        vals.append(vv[mine])
+    row_block = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                              shape=(m_loc, n_total))
+    row_block.sort_indices()
+    return col_block, row_block
+
+
+def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_000, k: int = 8,
+             seed: int = 5, structure: str = "staircase", window: int = 4096) -> LPShard:
+    """Rank-local part of one global m x (world*n_block) LP (weak scaling): column block ``rank``
+    in CSC and row block ``rank`` (m/world rows) in CSR, generated without generating the other
+    ranks' blocks.  ``structure`` is "staircase" (netlib-style, default) or "uniform" (no
+    locality).  world must divide 8 (staircase) / k (uniform) and k must divide m."""
+    if structure == "uniform":
+        if k % world or m % k:
+            raise ValueError("world must divide k and k must divide m")
+        col_block, row_block = _uniform_blocks(rank, world, m, n_block, k, seed)
+    elif structure == "staircase":
+        if STAIR_REGIONS % world or m % STAIR_REGIONS:
+            raise ValueError("world must divide 8 and 8 must divide m")
+        col_block, row_block = _staircase_blocks(rank, world, m, n_block, k, seed, window)
+    else:
+        raise ValueError("structure must be 'staircase' or 'uniform'")
+    m_loc = row_block.shape[0]
     # ---- vectors
     rng = np.random.default_rng([seed, 7777])
     y = rng.standard_normal(m)
