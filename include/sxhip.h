@@ -174,6 +174,46 @@ int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double 
 int sx_price(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
              const int8_t *vbasis, double tol, double *rc, sx_price_result *result);
 
+/* ------------------------------------------------------------------ K6 / K12: sub-problem
+ * replaces LPManager.fix_variables + update_subproblem (lp_methods/lp_manager.py:40-66) and
+ * MCFManagerStd.update_subproblem (network_methods/net_manager.py:202-209).
+ * sx_compact_columns_dev: non_fix = ascending columns with code[j] == 0 (device int64, room for n;
+ *   *n_sub receives the count on the host); *A_sub = A[:, non_fix] as a new resident matrix (CSR and
+ *   CSC, entry order preserved, destroy with sx_matrix_destroy).  Blocking (sizes come back to the
+ *   host to allocate the result).
+ * sx_fixed_rhs_dev: b_sub = b - A[:, up] @ u[up] - A[:, low] @ l[low] with up / low = columns whose
+ *   code has SX_CODE_UP / SX_CODE_LOW, bit-exact with the reference's two column-sliced products.
+ * sx_gather_f64_dev: dst[k] = src[idx[k]]  (c, l, u of the sub-problem; get_subx). */
+int sx_compact_columns_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t *code, sx_matrix **A_sub,
+                           int64_t *non_fix, int64_t *n_sub);
+int sx_fixed_rhs_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t *code, const double *u,
+                     const double *l, const double *b, double *b_sub);
+int sx_gather_f64_dev(sx_ctx *ctx, int64_t n, const int64_t *idx, const double *src, double *dst);
+
+/* ------------------------------------------------------------------ K4: projector norm
+ * replaces get_projector_Xc / apply_projector (lp_methods/algorithms.py:162-172,183-187; the
+ * no-free-variable branch) and feeds get_scale_factor (:190-193):
+ *     Y = [A, I_<] diag(xx),  v = diag(xx) c_std,  proj = v - Y^T cg(Y Y^T, Y v, tol, maxiter)
+ * xa = xx[:n]; xs = the slack part of xx scattered to a length-m vector (entry i = xx of the slack
+ * of row i when row i is '<', 0 when it is '='); c = structural costs (slack costs are 0).
+ * The device never forms Y Y^T: each CG iteration is one CSC and one CSR pass over A.  Stopping
+ * rule of the reference's scipy: x0 = 0; return at once when ||Yv|| <= tol; stop when
+ * ||r|| < tol*||Yv|| (tested before every iteration) or after maxiter iterations.
+ * Blocking call (the host polls a device flag every 25 iterations); _dev takes device pointers.
+ * Floating-point contract: proj_norm agrees with the reference to 1e-6 relative when CG converges
+ * (the reference's own explicit-YY^T arithmetic differs from any matrix-free one at that level). */
+typedef struct sx_cg_result {
+    double proj_norm;    /* ||proj||_2 */
+    double b_norm;       /* ||Y v||_2 */
+    double rel_residual; /* ||r|| / ||Y v|| at exit */
+    int64_t iters;       /* completed CG iterations */
+    int64_t converged;   /* 1 when the stopping rule fired, 0 when maxiter was hit */
+} sx_cg_result;
+int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                          const double *c, double tol, int maxiter, sx_cg_result *result);
+int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                      const double *c, double tol, int maxiter, sx_cg_result *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,372 @@
+// K4: norm of the projection (I - Y^T (Y Y^T)^+ Y) v with Y = [A, I_<] diag(xx), v = diag(xx) c_std,
+// by matrix-free conjugate gradients on the device (reference: get_projector_Xc / apply_projector /
+// get_scale_factor, lp_methods/algorithms.py:162-193, which forms Y Y^T explicitly and calls
+// scipy's cg with tol=1e-8, maxiter=1000).
+//
+// With xa = xx[:n] (structural columns) and xs = xx[n:] scattered to the '<' rows (0 elsewhere):
+//     (Y Y^T) p = A (xa^2 .* (A^T p)) + xs^2 .* p          b = Y v = A (xa^2 .* c)
+//     proj      = [ xa .* (c - A^T z) ;  -xs .* z ]         (slack costs are zero)
+// One CG iteration is four launches: CSC pass (w), CSR pass (q, partial p.q), update of z and r
+// (partial r.r), update of p.  Scalars live in device memory; every kernel returns at once when the
+// `done` flag is set, so the host enqueues iterations in batches and polls the flag between batches.
+// Reductions are two-stage with a fixed order: results are reproducible run to run.  The recurrence
+// and the stopping rule (||r|| < tol*||b||, tested before each iteration; legacy immediate exit when
+// ||b|| <= tol) are those of the reference's pinned scipy.
+#include "sx_internal.h"
+#include "sx_segwalk.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int CG_CHUNK = 4096;
+constexpr int CG_GRID = 2048; // workgroups of the grid-stride SpMV passes = number of partials
+
+struct CgState {
+    double rho[2];     // r.r of the current / next iteration (indexed by iteration parity)
+    double atol;       // tol * ||b||
+    double sumsq;      // final ||proj||^2
+    long long iters;   // completed iterations
+    int done;          // 1: converged (or finished), kernels become no-ops
+    int converged;
+};
+
+struct StageDot {
+    const double *__restrict__ vec;
+    __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[1]) const {
+        o[0] = v * vec[i];
+    }
+};
+
+__device__ __forceinline__ void walk_range(int64_t ntiles, int swizzle, int64_t &t, int64_t &t_end,
+                                           int64_t &t_step) {
+    t = blockIdx.x;
+    t_end = ntiles;
+    t_step = gridDim.x;
+    if (swizzle) {
+        const int64_t per = (ntiles + 7) >> 3;
+        t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        t_end = ((blockIdx.x & 7) + 1) * per;
+        if (t_end > ntiles) t_end = ntiles;
+        t_step = gridDim.x >> 3;
+    }
+}
+
+// fixed-order block sum; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v) {
+    __shared__ double s[SX_WG / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads(); // protect s[] against the previous use
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s[0] + s[1] + s[2] + s[3];
+}
+
+// every workgroup re-reduces the partial array in the same order -> identical value everywhere
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ partial, int np) {
+    double v = 0.0;
+    for (int k = threadIdx.x; k < np; k += SX_WG) v += partial[k];
+    double tot = block_sum(v);
+    __shared__ double bc;
+    if (threadIdx.x == 0) bc = tot;
+    __syncthreads();
+    return bc;
+}
+
+// out[j] = scale[j]^2 * (A^T in)[j]                                     (CSC pass)
+__global__ __launch_bounds__(SX_WG) void k_cg_at(const CgState *st, const int64_t *__restrict__ tiles,
+                                                 int64_t ntiles, int swizzle,
+                                                 const int64_t *__restrict__ colptr,
+                                                 const int32_t *__restrict__ rowidx,
+                                                 const double *__restrict__ val,
+                                                 const double *__restrict__ in,
+                                                 const double *__restrict__ scale,
+                                                 double *__restrict__ out) {
+    if (st->done) return;
+    __shared__ sx_walk_lds<1, CG_CHUNK> lds;
+    int64_t t, t_end, t_step;
+    walk_range(ntiles, swizzle, t, t_end, t_step);
+    for (; t < t_end; t += t_step) {
+        double acc[1];
+        int64_t j;
+        bool valid;
+        sx_segwalk<1, CG_CHUNK>(tiles, t, colptr, rowidx, val, StageDot{in}, lds, j, valid, acc);
+        if (valid) {
+            const double s = scale[j];
+            out[j] = (s * s) * acc[0];
+        }
+    }
+}
+
+// q[i] = (A w)[i] + xs[i]^2 * p[i];  partial[block] = sum p[i]*q[i]       (CSR pass)
+// with p == nullptr: q = A w only, partial = sum q[i]^2  (used for b = Y v and rho0 = b.b)
+__global__ __launch_bounds__(SX_WG) void k_cg_a(const CgState *st, const int64_t *__restrict__ tiles,
+                                                int64_t ntiles, int swizzle,
+                                                const int64_t *__restrict__ rowptr,
+                                                const int32_t *__restrict__ colidx,
+                                                const double *__restrict__ val,
+                                                const double *__restrict__ w,
+                                                const double *__restrict__ xs,
+                                                const double *__restrict__ p, double *__restrict__ q,
+                                                double *__restrict__ partial) {
+    if (st->done) return;
+    __shared__ sx_walk_lds<1, CG_CHUNK> lds;
+    int64_t t, t_end, t_step;
+    walk_range(ntiles, swizzle, t, t_end, t_step);
+    double dot = 0.0;
+    for (; t < t_end; t += t_step) {
+        double acc[1];
+        int64_t i;
+        bool valid;
+        sx_segwalk<1, CG_CHUNK>(tiles, t, rowptr, colidx, val, StageDot{w}, lds, i, valid, acc);
+        if (valid) {
+            double qi = acc[0];
+            if (p) {
+                const double s = xs[i], pi = p[i];
+                qi = qi + (s * s) * pi;
+                dot += pi * qi;
+            } else {
+                dot += qi * qi;
+            }
+            q[i] = qi;
+        }
+    }
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// t[j] = xa[j]^2 * c[j]
+__global__ __launch_bounds__(SX_WG) void k_cg_scale_c(int64_t n, const double *__restrict__ xa,
+                                                      const double *__restrict__ c,
+                                                      double *__restrict__ t) {
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG)
+        t[j] = (xa[j] * xa[j]) * c[j];
+}
+
+// start: r = p = b (already in r), z = 0, rho[0] = sum(partial)
+__global__ __launch_bounds__(SX_WG) void k_cg_init(CgState *st, int64_t m, const double *__restrict__ partial,
+                                                   int np, const double *__restrict__ r,
+                                                   double *__restrict__ p, double *__restrict__ z) {
+    const double rho0 = reduce_partials(partial, np);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        p[i] = r[i];
+        z[i] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rho[0] = rho0;
+        st->rho[1] = 0.0;
+        st->iters = 0;
+        st->done = 0;
+        st->converged = 0;
+        st->sumsq = 0.0;
+        st->atol = 0.0; // set by the host once it knows ||b||
+    }
+}
+
+// alpha = rho / (p.q);  z += alpha p;  r -= alpha q;  partial_rr[block] = sum r^2
+__global__ __launch_bounds__(SX_WG) void k_cg_update_zr(const CgState *st, int parity, int64_t m,
+                                                        const double *__restrict__ partial_pq, int np,
+                                                        const double *__restrict__ p,
+                                                        const double *__restrict__ q,
+                                                        double *__restrict__ z, double *__restrict__ r,
+                                                        double *__restrict__ partial_rr) {
+    if (st->done) return;
+    const double pq = reduce_partials(partial_pq, np);
+    const double alpha = st->rho[parity] / pq;
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        z[i] = z[i] + alpha * p[i];
+        const double ri = r[i] - alpha * q[i];
+        r[i] = ri;
+        acc += ri * ri;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial_rr[blockIdx.x] = tot;
+}
+
+// rho' = sum(partial_rr); stop test; beta = rho'/rho; p = r + beta p
+__global__ __launch_bounds__(SX_WG) void k_cg_update_p(CgState *st, int parity, int64_t m,
+                                                       const double *__restrict__ partial_rr, int np,
+                                                       const double *__restrict__ r,
+                                                       double *__restrict__ p) {
+    if (st->done) return;
+    const double rho_new = reduce_partials(partial_rr, np);
+    const double rho_old = st->rho[parity];
+    const bool stop = sqrt(rho_new) < st->atol;
+    if (!stop) {
+        const double beta = rho_new / rho_old;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+             i += static_cast<int64_t>(gridDim.x) * SX_WG)
+            p[i] = r[i] + beta * p[i]; // scipy: p *= beta; p += r  (same two roundings)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rho[parity ^ 1] = rho_new;
+        st->iters = st->iters + 1;
+        if (stop) {
+            st->converged = 1;
+            __threadfence();
+            st->done = 1;
+        }
+    }
+}
+
+// partial[block] = sum_j (xa[j] * (c[j] - (A^T z)[j]))^2
+__global__ __launch_bounds__(SX_WG) void k_cg_proj_cols(int64_t n, const double *__restrict__ xa,
+                                                        const double *__restrict__ c,
+                                                        const double *__restrict__ atz,
+                                                        double *__restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double pj = xa[j] * (c[j] - atz[j]);
+        acc += pj * pj;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SX_WG) void k_cg_proj_rows(int64_t m, const double *__restrict__ xs,
+                                                        const double *__restrict__ z,
+                                                        double *__restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double pi = xs[i] * z[i];
+        acc += pi * pi;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SX_WG) void k_cg_finish(CgState *st, const double *__restrict__ pa, int na,
+                                                     const double *__restrict__ pb, int nb) {
+    const double a = reduce_partials(pa, na);
+    const double b = reduce_partials(pb, nb);
+    if (threadIdx.x == 0) st->sumsq = a + b;
+}
+
+__global__ void k_cg_set_atol(CgState *st, double atol, int done) {
+    st->atol = atol;
+    st->done = done;
+}
+
+__global__ void k_cg_ones(int64_t n, double *v) {
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG)
+        v[j] = 1.0;
+}
+
+inline int grid_for(const sx_ctx *ctx, int64_t ntiles) {
+    int64_t g = ntiles < CG_GRID ? ntiles : CG_GRID;
+    if (ctx->opt_xcd_swizzle && ntiles >= 64) g &= ~static_cast<int64_t>(7);
+    return static_cast<int>(g < 1 ? 1 : g);
+}
+
+} // namespace
+
+SX_API int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                                 const double *c, double tol, int maxiter, sx_cg_result *result) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr && result != nullptr, "matrix or result is NULL");
+    SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the projector needs both layouts of A");
+    SX_REQUIRE(xa && xs && c, "xa, xs or c is NULL");
+    SX_REQUIRE(maxiter >= 0 && tol >= 0, "bad tol/maxiter");
+    const int64_t m = A->m, n = A->n;
+    memset(result, 0, sizeof(*result));
+    if (m == 0 || n == 0) return SX_OK;
+
+    const int swzT = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
+    const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64) ? 1 : 0;
+    const int gT = grid_for(ctx, A->n_csc_tiles), gA = grid_for(ctx, A->n_csr_tiles);
+    const int gv = 1024; // vector kernels: grid-stride, 1024 partials
+
+    // workspace: state | partial_pq[CG_GRID] | partial_rr[CG_GRID] | z r p q [m] | w atz [n]
+    const size_t off_state = 0;
+    const size_t off_ppq = 256;
+    const size_t off_prr = off_ppq + sizeof(double) * CG_GRID;
+    const size_t off_vec = off_prr + sizeof(double) * CG_GRID;
+    const size_t bytes =
+        off_vec + sizeof(double) * (4 * static_cast<size_t>(m) + 2 * static_cast<size_t>(n)) + 256;
+    SX_TRY(sx_reserve(ctx, bytes));
+    char *base = static_cast<char *>(ctx->ws);
+    CgState *st = reinterpret_cast<CgState *>(base + off_state);
+    double *ppq = reinterpret_cast<double *>(base + off_ppq);
+    double *prr = reinterpret_cast<double *>(base + off_prr);
+    double *z = reinterpret_cast<double *>(base + off_vec);
+    double *r = z + m, *p = r + m, *q = p + m, *w = q + m, *atz = w + n;
+    hipStream_t s = ctx->stream;
+
+    SX_HIP(hipMemsetAsync(st, 0, sizeof(CgState), s));
+    // b = A (xa^2 .* c) -> r ; rho0 = b.b
+    hipLaunchKernelGGL(k_cg_scale_c, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, w);
+    hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
+                       A->csr_ptr, A->csr_idx, A->csr_val, w, xs, static_cast<const double *>(nullptr), r, ppq);
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(SX_WG), 0, s, st, m, ppq, gA, r, p, z);
+    CgState host;
+    SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    const double bnrm = sqrt(host.rho[0]);
+    result->b_norm = bnrm;
+    const bool trivial = !(bnrm > tol); // legacy scipy: ||b|| <= tol -> return x0 = 0 at once
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, st, tol * bnrm, trivial ? 1 : 0);
+
+    int launched = 0;
+    bool finished = trivial;
+    if (!trivial && !(bnrm < tol * bnrm)) { // scipy tests ||r|| < atol before the first iteration too
+        const int batch = 25;
+        while (launched < maxiter && !finished) {
+            const int upto = (launched + batch < maxiter) ? launched + batch : maxiter;
+            for (; launched < upto; ++launched) {
+                const int par = launched & 1;
+                hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles,
+                                   swzT, A->csc_ptr, A->csc_idx, A->csc_val, p, xa, w);
+                hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles,
+                                   swzA, A->csr_ptr, A->csr_idx, A->csr_val, w, xs, p, q, ppq);
+                hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, gA, p, q,
+                                   z, r, prr);
+                hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(SX_WG), 0, s, st, par, m, prr, gv, r, p);
+            }
+            SX_HIP(hipGetLastError());
+            SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+            SX_HIP(hipStreamSynchronize(s));
+            finished = host.done != 0;
+        }
+    }
+    SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    result->iters = host.iters;
+    result->converged = trivial ? 1 : host.converged;
+    result->rel_residual = bnrm > 0 ? sqrt(host.rho[host.iters & 1]) / bnrm : 0.0;
+
+    // ||proj||: columns xa .* (c - A^T z), slack rows -xs .* z.  A^T z is taken with unit scale
+    // (dividing xa^2 (A^T z) by xa would break on xa = 0), so w becomes a vector of ones first.
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, st, tol * bnrm, 0); // re-arm the kernels
+    hipLaunchKernelGGL(k_cg_ones, dim3(gv), dim3(SX_WG), 0, s, n, w);
+    hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
+                       A->csc_ptr, A->csc_idx, A->csc_val, z, w, atz);
+    hipLaunchKernelGGL(k_cg_proj_cols, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, atz, ppq);
+    hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, z, prr);
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, st, ppq, gv, prr, gv);
+    SX_HIP(hipGetLastError());
+    SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    result->proj_norm = sqrt(host.sumsq);
+    return SX_OK;
+}
+
+SX_API int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                             const double *c, double tol, int maxiter, sx_cg_result *result) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr && result != nullptr, "matrix or result is NULL");
+    SX_REQUIRE(xa && xs && c, "xa, xs or c is NULL");
+    sx_stage st(ctx);
+    void *dxa, *dxs, *dc;
+    SX_TRY(st.in(xa, sizeof(double) * A->n, &dxa));
+    SX_TRY(st.in(xs, sizeof(double) * A->m, &dxs));
+    SX_TRY(st.in(c, sizeof(double) * A->n, &dc));
+    return sx_projector_norm_dev(ctx, A, (double *)dxa, (double *)dxs, (double *)dc, tol, maxiter, result);
+}

@@ -164,6 +164,33 @@ class Context:
                                         result.ptr))
         return result
 
+    def compact_columns(self, A, code: "DeviceArray"):
+        """K6 (blocking): returns (A_sub as DeviceMatrix, non_fix as DeviceArray[int64] of length n_sub)."""
+        non_fix = self.empty(max(A.shape[1], 1), np.int64)
+        h = C.c_void_p()
+        nsub = C.c_int64(0)
+        _l.check(self._lib.sx_compact_columns_dev(self.handle, A.handle, code.ptr, C.byref(h), non_fix.ptr,
+                                                  C.byref(nsub)))
+        non_fix.size = int(nsub.value)
+        non_fix.nbytes = non_fix.size * 8
+        return DeviceMatrix.from_handle(self, h), non_fix
+
+    def fixed_rhs(self, A, code, u, l, b, b_sub) -> None:
+        _l.check(self._lib.sx_fixed_rhs_dev(self.handle, A.handle, _ptr(code), _ptr(u), _ptr(l), _ptr(b), _ptr(b_sub)))
+
+    def gather(self, idx: "DeviceArray", src: "DeviceArray", dst: Optional["DeviceArray"] = None) -> "DeviceArray":
+        if dst is None:
+            dst = self.empty(idx.size, np.float64)
+        _l.check(self._lib.sx_gather_f64_dev(self.handle, idx.size, idx.ptr, src.ptr, dst.ptr))
+        return dst
+
+    def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000) -> "_l.CgResult":
+        """K4 (blocking): ||(I - Y^T (YY^T)^+ Y) v|| by matrix-free CG; device pointers in."""
+        res = _l.CgResult()
+        _l.check(self._lib.sx_projector_norm_dev(self.handle, A.handle, _ptr(xa), _ptr(xs), _ptr(c), float(tol),
+                                                 int(maxiter), C.byref(res)))
+        return res
+
     @staticmethod
     def read_price(result: "DeviceArray") -> Tuple[float, int, int]:
         raw = result.download()

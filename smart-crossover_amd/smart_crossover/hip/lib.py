@@ -35,6 +35,11 @@ class PriceResult(C.Structure):
     _fields_ = [("min_rc", C.c_double), ("argmin", C.c_int64), ("n_violating", C.c_int64)]
 
 
+class CgResult(C.Structure):
+    _fields_ = [("proj_norm", C.c_double), ("b_norm", C.c_double), ("rel_residual", C.c_double),
+                ("iters", C.c_int64), ("converged", C.c_int64)]
+
+
 _vp = C.c_void_p
 _i64 = C.c_int64
 _dbl = C.c_double
@@ -78,6 +83,11 @@ PROTOTYPES = {
     "sx_perturb_cost": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp]),
     "sx_price_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "sx_price": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, C.POINTER(PriceResult)]),
+    "sx_compact_columns_dev": (_int, [_vp, _vp, _vp, C.POINTER(_vp), _vp, C.POINTER(_i64)]),
+    "sx_fixed_rhs_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sx_gather_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
+    "sx_projector_norm": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
 }
 
 _lib: Optional[C.CDLL] = None
