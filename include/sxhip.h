@@ -190,6 +190,37 @@ int sx_fixed_rhs_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t *code, const
                      const double *l, const double *b, double *b_sub);
 int sx_gather_f64_dev(sx_ctx *ctx, int64_t n, const int64_t *idx, const double *src, double *dst);
 
+/* ------------------------------------------------------------------ K7: MCF flow indicators
+ * replaces the arithmetic of MCFManagerStd.get_sorted_flows (network_methods/net_manager.py:165-182):
+ *     mask = x > u/2;  x_hat = x*(~mask) + u*mask - x*mask, 0 where x < 0 or x > u
+ *     a_bar = -a on masked arcs;  f_i = max(sum_{a_bar>0} a_bar*x_hat, sum_{a_bar<0} |a_bar|*x_hat)
+ *     ind_j = max_i |(f_inv_i * x_hat_j) * a_bar_ij|,  f_inv = 1/f where f != 0 else 0
+ * node sums run over the arcs of a node in stored CSR order (canonical = ascending arc), bit-exact
+ * with the reference for matrices in canonical form.  A: V x E with both layouts; x, u, ind: E.
+ * xhat_out (E) and f_out (V) are optional outputs of the intermediates (NULL to skip). */
+int sx_flow_indicator_mcf_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, const double *u,
+                              double *ind, double *xhat_out, double *f_out);
+
+/* ------------------------------------------------------------------ K8: OT flow indicators
+ * replaces OTManager.get_sorted_flows (network_methods/net_manager.py:377-378):
+ *     ind[i*D + j] = max(X[i*D+j] / s[i], X[i*D+j] / d[j])    (IEEE division, numpy.maximum) */
+int sx_flow_indicator_ot_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *X, const double *s,
+                             const double *d, double *ind);
+
+/* ------------------------------------------------------------------ K9: ranking
+ * replaces np.argsort(indicators)[::-1] (network_methods/net_manager.py:184,379).  The reference's
+ * default sort is unstable, so ties are defined here: descending key; equal keys by descending
+ * index (== np.argsort(key, kind="stable")[::-1]); NaN ranks first.  idx_out: n int64.  Blocking. */
+int sx_argsort_desc_dev(sx_ctx *ctx, int64_t n, const double *key, int64_t *idx_out);
+
+/* ------------------------------------------------------------------ K10 on the OT structure
+ * replaces get_reduced_cost_for_original_OT + the reduced-cost test (network_methods/net_manager.py:
+ * 483,496) without materialising the kron incidence matrix of formats.py:156-159:
+ *     rc[i*D + j] = M[i*D + j] - ((0 + (-1)*y[i]) + (+1)*y[S + j])
+ * y has S + D entries (more are ignored); rc may be NULL; result as in sx_price_dev. */
+int sx_price_ot_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *M, const double *y, double tol,
+                    double *rc, sx_price_result *result_dev);
+
 /* ------------------------------------------------------------------ K4: projector norm
  * replaces get_projector_Xc / apply_projector (lp_methods/algorithms.py:162-172,183-187; the
  * no-free-variable branch) and feeds get_scale_factor (:190-193):

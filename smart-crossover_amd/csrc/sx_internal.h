@@ -85,6 +85,8 @@ struct sx_matrix {
 
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
                    int64_t *ntiles_out);
+// exclusive scan of in[0..n) into out[0..n] (out[n] = total); uses ctx->ws (sx_compact.hip)
+int sx_scan_exclusive(sx_ctx *ctx, const int64_t *in, int64_t n, int64_t *out);
 
 // RAII guard: make the context's device current for the duration of a call.
 struct sx_device_guard {

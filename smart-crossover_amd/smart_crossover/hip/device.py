@@ -184,6 +184,26 @@ class Context:
         _l.check(self._lib.sx_gather_f64_dev(self.handle, idx.size, idx.ptr, src.ptr, dst.ptr))
         return dst
 
+    def flow_indicator_mcf(self, A, x, u, ind, xhat=None, f=None) -> None:
+        _l.check(self._lib.sx_flow_indicator_mcf_dev(self.handle, A.handle, _ptr(x), _ptr(u), _ptr(ind), _ptr(xhat),
+                                                     _ptr(f)))
+
+    def flow_indicator_ot(self, S, D, X, s, d, ind) -> None:
+        _l.check(self._lib.sx_flow_indicator_ot_dev(self.handle, int(S), int(D), _ptr(X), _ptr(s), _ptr(d), _ptr(ind)))
+
+    def argsort_desc(self, key: "DeviceArray", out: Optional["DeviceArray"] = None) -> "DeviceArray":
+        if out is None:
+            out = self.empty(key.size, np.int64)
+        _l.check(self._lib.sx_argsort_desc_dev(self.handle, key.size, key.ptr, out.ptr))
+        return out
+
+    def price_ot(self, S, D, M, y, tol=1e-6, rc=None, result: Optional["DeviceArray"] = None):
+        if result is None:
+            result = self.empty(C.sizeof(_l.PriceResult), np.uint8)
+        _l.check(self._lib.sx_price_ot_dev(self.handle, int(S), int(D), _ptr(M), _ptr(y), float(tol), _ptr(rc),
+                                           result.ptr))
+        return result
+
     def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000) -> "_l.CgResult":
         """K4 (blocking): ||(I - Y^T (YY^T)^+ Y) v|| by matrix-free CG; device pointers in."""
         res = _l.CgResult()

@@ -86,6 +86,10 @@ PROTOTYPES = {
     "sx_compact_columns_dev": (_int, [_vp, _vp, _vp, C.POINTER(_vp), _vp, C.POINTER(_i64)]),
     "sx_fixed_rhs_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_gather_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "sx_flow_indicator_mcf_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sx_flow_indicator_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sx_argsort_desc_dev": (_int, [_vp, _i64, _vp, _vp]),
+    "sx_price_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _dbl, _vp, _vp]),
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
     "sx_projector_norm": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
 }
