@@ -242,6 +242,19 @@ typedef struct sx_cg_result {
 } sx_cg_result;
 int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                           const double *c, double tol, int maxiter, sx_cg_result *result);
+/* same, also returning the projection itself: proj_cols[n] = xa .* (c - A^T z) and
+ * proj_rows[m] = -xs .* z (device pointers, either may be NULL) -- what apply_projector returns
+ * (lp_methods/algorithms.py:187), with the slack block scattered to row positions */
+int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                     const double *c, double tol, int maxiter, double *proj_cols, double *proj_rows,
+                     sx_cg_result *result);
+/* get_x_perturb_val (lp_methods/algorithms.py:196-202): min(x-l, u-x), free columns -> x; with
+ * apply_floor != 0 also the two overwrites of perturb_c (:131-132): values < 1e-6 -> 1e-6, free
+ * columns -> 1 */
+int sx_x_real_dev(sx_ctx *ctx, int64_t n, const double *x, const double *l, const double *u,
+                  int apply_floor, double *x_real);
+/* dst[i] = mask[i] ? src[i] : 0 */
+int sx_mask_f64_dev(sx_ctx *ctx, int64_t n, const double *src, const uint8_t *mask, double *dst);
 int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                       const double *c, double tol, int maxiter, sx_cg_result *result);
 

@@ -218,11 +218,13 @@ __global__ __launch_bounds__(SX_WG) void k_cg_update_p(CgState *st, int parity, 
 __global__ __launch_bounds__(SX_WG) void k_cg_proj_cols(int64_t n, const double *__restrict__ xa,
                                                         const double *__restrict__ c,
                                                         const double *__restrict__ atz,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial,
+                                                        double *__restrict__ proj_out) {
     double acc = 0.0;
     for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
          j += static_cast<int64_t>(gridDim.x) * SX_WG) {
         const double pj = xa[j] * (c[j] - atz[j]);
+        if (proj_out) proj_out[j] = pj;
         acc += pj * pj;
     }
     const double tot = block_sum(acc);
@@ -231,11 +233,13 @@ __global__ __launch_bounds__(SX_WG) void k_cg_proj_cols(int64_t n, const double 
 
 __global__ __launch_bounds__(SX_WG) void k_cg_proj_rows(int64_t m, const double *__restrict__ xs,
                                                         const double *__restrict__ z,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial,
+                                                        double *__restrict__ proj_out) {
     double acc = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
          i += static_cast<int64_t>(gridDim.x) * SX_WG) {
         const double pi = xs[i] * z[i];
+        if (proj_out) proj_out[i] = -pi; // slack block of proj is -xs .* z (slack costs are zero)
         acc += pi * pi;
     }
     const double tot = block_sum(acc);
@@ -268,8 +272,9 @@ inline int grid_for(const sx_ctx *ctx, int64_t ntiles) {
 
 } // namespace
 
-SX_API int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
-                                 const double *c, double tol, int maxiter, sx_cg_result *result) {
+SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                            const double *c, double tol, int maxiter, double *proj_cols,
+                            double *proj_rows, sx_cg_result *result) {
     SX_ENTER(ctx);
     SX_REQUIRE(A != nullptr && result != nullptr, "matrix or result is NULL");
     SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the projector needs both layouts of A");
@@ -348,14 +353,19 @@ SX_API int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     hipLaunchKernelGGL(k_cg_ones, dim3(gv), dim3(SX_WG), 0, s, n, w);
     hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
                        A->csc_ptr, A->csc_idx, A->csc_val, z, w, atz);
-    hipLaunchKernelGGL(k_cg_proj_cols, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, atz, ppq);
-    hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, z, prr);
+    hipLaunchKernelGGL(k_cg_proj_cols, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, atz, ppq, proj_cols);
+    hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, z, prr, proj_rows);
     hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, st, ppq, gv, prr, gv);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
     result->proj_norm = sqrt(host.sumsq);
     return SX_OK;
+}
+
+SX_API int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                                 const double *c, double tol, int maxiter, sx_cg_result *result) {
+    return sx_projector_dev(ctx, A, xa, xs, c, tol, maxiter, nullptr, nullptr, result);
 }
 
 SX_API int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,

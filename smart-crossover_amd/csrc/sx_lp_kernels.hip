@@ -289,6 +289,35 @@ __global__ __launch_bounds__(SX_WG) void k_perturb_cost(int64_t n, const double 
     }
 }
 
+// x_real of perturb_c (lp_methods/algorithms.py:130-132 after :196-202): distance to the nearer
+// bound, free columns keep x for the floor test, floor at 1e-6, free columns end at 1
+__global__ __launch_bounds__(SX_WG) void k_x_real(int64_t n, const double *__restrict__ x,
+                                                  const double *__restrict__ l,
+                                                  const double *__restrict__ u, int apply_floor,
+                                                  double *__restrict__ x_real) {
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double xj = x[j], lj = l[j], uj = u[j];
+        const bool is_free = (lj == -INFINITY) && (uj == INFINITY);
+        double xr = np_minimum(xj - lj, uj - xj);
+        if (is_free) xr = xj;
+        if (apply_floor) {
+            if (xr < 1e-6) xr = 1e-6;
+            if (is_free) xr = 1.0;
+        }
+        x_real[j] = xr;
+    }
+}
+
+// dst[i] = mask[i] ? src[i] : 0   (slack part of the standard-form vector scattered to all rows)
+__global__ __launch_bounds__(SX_WG) void k_mask_f64(int64_t n, const double *__restrict__ src,
+                                                    const uint8_t *__restrict__ mask,
+                                                    double *__restrict__ dst) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG)
+        dst[i] = mask[i] ? src[i] : 0.0;
+}
+
 // grid of a one-tile-per-workgroup launch: with the XCD swizzle every XCD gets ceil(T/8) slots
 inline unsigned walk_grid(const sx_ctx *ctx, int64_t ntiles) {
     if (!ctx->opt_xcd_swizzle) return static_cast<unsigned>(ntiles);
@@ -385,6 +414,32 @@ SX_API int sx_perturb_cost_dev(sx_ctx *ctx, int64_t n, const double *x, const do
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(k_perturb_cost, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream,
                        n, x, l, u, c, xi, scale_factor, is_feas, c_pt);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_x_real_dev(sx_ctx *ctx, int64_t n, const double *x, const double *l, const double *u,
+                         int apply_floor, double *x_real) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return SX_OK;
+    SX_REQUIRE(x && l && u && x_real, "NULL argument");
+    int64_t nb = (n + SX_WG - 1) / SX_WG;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_x_real, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream, n, x, l, u,
+                       apply_floor, x_real);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_mask_f64_dev(sx_ctx *ctx, int64_t n, const double *src, const uint8_t *mask, double *dst) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return SX_OK;
+    SX_REQUIRE(src && mask && dst, "NULL argument");
+    int64_t nb = (n + SX_WG - 1) / SX_WG;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_mask_f64, dim3(static_cast<unsigned>(nb)), dim3(SX_WG), 0, ctx->stream, n, src, mask, dst);
     SX_HIP(hipGetLastError());
     return SX_OK;
 }

@@ -204,12 +204,20 @@ class Context:
                                            result.ptr))
         return result
 
-    def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000) -> "_l.CgResult":
-        """K4 (blocking): ||(I - Y^T (YY^T)^+ Y) v|| by matrix-free CG; device pointers in."""
+    def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000, proj_cols=None, proj_rows=None) -> "_l.CgResult":
+        """K4 (blocking): ||(I - Y^T (YY^T)^+ Y) v|| by matrix-free CG; device pointers in; the
+        projection itself lands in proj_cols[n] / proj_rows[m] when given."""
         res = _l.CgResult()
-        _l.check(self._lib.sx_projector_norm_dev(self.handle, A.handle, _ptr(xa), _ptr(xs), _ptr(c), float(tol),
-                                                 int(maxiter), C.byref(res)))
+        _l.check(self._lib.sx_projector_dev(self.handle, A.handle, _ptr(xa), _ptr(xs), _ptr(c), float(tol),
+                                            int(maxiter), _ptr(proj_cols), _ptr(proj_rows), C.byref(res)))
         return res
+
+    def x_real(self, n, x, l, u, out, apply_floor: bool = True) -> None:
+        _l.check(self._lib.sx_x_real_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), int(bool(apply_floor)),
+                                         _ptr(out)))
+
+    def mask(self, src: "DeviceArray", mask: "DeviceArray", dst: "DeviceArray") -> None:
+        _l.check(self._lib.sx_mask_f64_dev(self.handle, src.size, src.ptr, mask.ptr, dst.ptr))
 
     @staticmethod
     def read_price(result: "DeviceArray") -> Tuple[float, int, int]:
