@@ -186,6 +186,12 @@ int sx_price(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
  * sx_gather_f64_dev: dst[k] = src[idx[k]]  (c, l, u of the sub-problem; get_subx). */
 int sx_compact_columns_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t *code, sx_matrix **A_sub,
                            int64_t *non_fix, int64_t *n_sub);
+/* A[:, idx] for an explicit list of nsub distinct columns in any order (device int64): column k of
+ * the result is column idx[k] of A; inside every row the entries keep their stored order, as scipy's
+ * CSR fancy column indexing does (the column-generation managers append released columns in queue
+ * order, network_methods/net_manager.py:204-205,242).  Blocking. */
+int sx_gather_columns_dev(sx_ctx *ctx, const sx_matrix *A, const int64_t *idx, int64_t nsub,
+                          sx_matrix **A_sub);
 int sx_fixed_rhs_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t *code, const double *u,
                      const double *l, const double *b, double *b_sub);
 int sx_gather_f64_dev(sx_ctx *ctx, int64_t n, const int64_t *idx, const double *src, double *dst);

@@ -278,19 +278,15 @@ SX_API int sx_compact_columns_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t
                                   sx_matrix **A_sub_out, int64_t *non_fix, int64_t *n_sub_out) {
     SX_ENTER(ctx);
     SX_REQUIRE(A && code && A_sub_out && non_fix && n_sub_out, "NULL argument");
-    SX_REQUIRE(A->csr_ptr && A->csc_ptr, "compaction needs both layouts of A");
     *A_sub_out = nullptr;
     *n_sub_out = 0;
-    const int64_t m = A->m, n = A->n;
+    const int64_t n = A->n;
     hipStream_t s = ctx->stream;
     scratch tmp;
     uint8_t *keep;
-    int64_t *count_dev, *len_c, *len_r;
-    int32_t *colmap;
+    int64_t *count_dev;
     SX_TRY(tmp.get(static_cast<size_t>(n) + 16, &keep));
     SX_TRY(tmp.get(1, &count_dev));
-    SX_TRY(tmp.get(static_cast<size_t>(n), &colmap));
-    SX_TRY(tmp.get(static_cast<size_t>(m), &len_r));
     int64_t nsub = 0;
     if (n > 0) {
         hipLaunchKernelGGL(k_keep_flags, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, code, keep);
@@ -298,6 +294,25 @@ SX_API int sx_compact_columns_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t
         SX_HIP(hipMemcpyAsync(&nsub, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         SX_HIP(hipStreamSynchronize(s));
     }
+    SX_TRY(sx_gather_columns_dev(ctx, A, non_fix, nsub, A_sub_out));
+    *n_sub_out = nsub;
+    return SX_OK;
+}
+
+SX_API int sx_gather_columns_dev(sx_ctx *ctx, const sx_matrix *A, const int64_t *non_fix, int64_t nsub,
+                                 sx_matrix **A_sub_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A && A_sub_out, "NULL argument");
+    SX_REQUIRE(nsub >= 0 && (nsub == 0 || non_fix), "bad column list");
+    SX_REQUIRE(A->csr_ptr && A->csc_ptr, "column gathering needs both layouts of A");
+    *A_sub_out = nullptr;
+    const int64_t m = A->m, n = A->n;
+    hipStream_t s = ctx->stream;
+    scratch tmp;
+    int64_t *len_c, *len_r;
+    int32_t *colmap;
+    SX_TRY(tmp.get(static_cast<size_t>(n), &colmap));
+    SX_TRY(tmp.get(static_cast<size_t>(m), &len_r));
     SX_TRY(tmp.get(static_cast<size_t>(nsub), &len_c));
 
     sx_matrix *S = new (std::nothrow) sx_matrix();
@@ -362,7 +377,6 @@ SX_API int sx_compact_columns_dev(sx_ctx *ctx, const sx_matrix *A, const uint8_t
         return rc;
     }
     *A_sub_out = S;
-    *n_sub_out = nsub;
     return SX_OK;
 }
 

@@ -175,6 +175,12 @@ class Context:
         non_fix.nbytes = non_fix.size * 8
         return DeviceMatrix.from_handle(self, h), non_fix
 
+    def gather_columns(self, A, idx: "DeviceArray") -> "DeviceMatrix":
+        """A[:, idx] for distinct columns in any order (blocking)."""
+        h = C.c_void_p()
+        _l.check(self._lib.sx_gather_columns_dev(self.handle, A.handle, idx.ptr, idx.size, C.byref(h)))
+        return DeviceMatrix.from_handle(self, h)
+
     def fixed_rhs(self, A, code, u, l, b, b_sub) -> None:
         _l.check(self._lib.sx_fixed_rhs_dev(self.handle, A.handle, _ptr(code), _ptr(u), _ptr(l), _ptr(b), _ptr(b_sub)))
 

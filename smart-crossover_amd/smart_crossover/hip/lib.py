@@ -84,6 +84,7 @@ PROTOTYPES = {
     "sx_price_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "sx_price": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, C.POINTER(PriceResult)]),
     "sx_compact_columns_dev": (_int, [_vp, _vp, _vp, C.POINTER(_vp), _vp, C.POINTER(_i64)]),
+    "sx_gather_columns_dev": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_vp)]),
     "sx_fixed_rhs_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_gather_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_flow_indicator_mcf_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
