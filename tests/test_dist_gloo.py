@@ -1,0 +1,45 @@
+"""CPU: the N > 1 path (column / row blocks, pricing all-gather, set-size all-reduce) rehearsed with
+two gloo ranks on 127.0.0.1 and compared with the single-process result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("structure", ["staircase", "uniform"])
+def test_two_rank_scoring_matches_single_process(tmp_path, structure):
+    out = tmp_path / "result.json"
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SX_STRUCTURE=structure, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(out)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            text, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(text.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = json.loads(out.read_text())
+    assert res["world"] == 2
+    assert res["codes_equal"] and res["flags_equal"]
+    assert res["counts"] == res["counts_want"] and sum(res["counts"]) > 0
+    assert res["price"] == res["price_want"]
+    assert res["slowest"] == 2.0
