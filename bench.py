@@ -191,6 +191,20 @@ def main():
     k1_bytes = 12 * nnz_loc + 49 * n_loc + 8 * m        # K1 algorithmic bytes
     achieved = k1_bytes / k1_avg_s / 1e9
 
+    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the
+    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/rNN/),
+    # corrected as MI355X_MICROARCH.md prescribes; null when no pass matches the workload
+    traffic = None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k_score_columns_traffic.json")), reverse=True):
+            rec = json.load(open(path))
+            if rec.get("workload") == f"{args.workload}/{structure}":
+                traffic = rec["traffic_bytes_per_launch"]
+                break
+    except Exception:
+        traffic = None
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_loc / (elapsed / args.steps)
 
@@ -235,7 +249,7 @@ def main():
                                                             + (" + all_gather(24B) + all_reduce(3xi64)" if world > 1 else ""),
                        "parallelism": f"column/row blocks over {world} GPU(s)"},
             "roofline": {"kernel": "k_score_columns", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": int(k1_bytes), "avg_kernel_ms": k1_avg_s * 1e3,
                          "min_kernel_ms": float(np.min(k1_ms))},
             "cpu_baseline": cpu,
