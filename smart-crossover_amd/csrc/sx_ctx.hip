@@ -85,6 +85,8 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "chunk")) {
         SX_REQUIRE(value == 2048 || value == 4096, "chunk must be 2048 or 4096");
         ctx->opt_chunk = static_cast<int>(value);
+    } else if (!strcmp(key, "window")) {
+        ctx->opt_window = value ? 1 : 0;
     } else {
         sx_set_error("unknown option '%s'", key);
         return SX_ERR_INVALID;
@@ -381,8 +383,8 @@ SX_API int sx_matrix_destroy(sx_matrix *A) {
     if (!A) return SX_OK;
     sx_device_guard guard(A->ctx->device);
     (void)hipStreamSynchronize(A->ctx->stream);
-    void *ptrs[8] = {A->csr_ptr, A->csr_idx, A->csr_val,   A->csc_ptr,
-                     A->csc_idx, A->csc_val, A->csr_tiles, A->csc_tiles};
+    void *ptrs[9] = {A->csr_ptr, A->csr_idx,   A->csr_val,   A->csc_ptr,   A->csc_idx,
+                     A->csc_val, A->csr_tiles, A->csc_tiles, A->csc_win_lo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete A;

@@ -63,6 +63,7 @@ struct sx_ctx {
     int opt_xcd_swizzle = 1; // XCD-contiguous block -> tile map
     int opt_nt_stream = 0;   // non-temporal loads for the streamed entry arrays
     int opt_chunk = 4096;    // staged entries per chunk (2048 or 4096)
+    int opt_window = 0;      // 1: per-tile LDS operand window in K1 (opt-in, see sx_window.hip)
 };
 
 int sx_reserve(sx_ctx *ctx, size_t bytes); // ensure ctx->ws holds >= bytes
@@ -81,7 +82,15 @@ struct sx_matrix {
     int64_t n_csr_tiles = 0;
     int64_t *csc_tiles = nullptr;
     int64_t n_csc_tiles = 0;
+    // optional per-tile operand window of the column walk (sx_window.hip), built on first use
+    mutable int32_t *csc_win_lo = nullptr;
+    mutable int csc_win_tried = 0;
 };
+
+int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
+                    int64_t bound, int32_t **win_lo_out);
+int sx_window_score_columns(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c, const double *x,
+                            const double *l, const double *u, double gamma, double *s_d, uint8_t *code);
 
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
                    int64_t *ntiles_out);

@@ -30,14 +30,25 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
     double acc[1];
     int64_t j;
     bool valid;
-    sx_segwalk<1, CHUNK, NT>(tiles, tile, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc);
+    // the epilogue's operands are requested before the walk so their latency hides under it
+    double cj = 0.0, xj = 0.0, lj = 0.0, uj = 0.0;
+    auto pre = [&](int64_t seg, bool ok) {
+        if (ok) {
+            cj = c[seg];
+            if (code) {
+                xj = x[seg];
+                lj = l[seg];
+                uj = u[seg];
+            }
+        }
+    };
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre);
     if (!valid) return;
-    const double sd = c[j] - acc[0];
+    const double sd = cj - acc[0];
     if (s_d) s_d[j] = sd;
     if (code) {
-        const double xj = x[j];
-        const bool low = (xj - l[j]) < (gamma * sd);
-        const bool up = (u[j] - xj) < (gamma * (-sd));
+        const bool low = (xj - lj) < (gamma * sd);
+        const bool up = (uj - xj) < (gamma * (-sd));
         code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
     }
 }
@@ -56,11 +67,18 @@ __global__ __launch_bounds__(SX_WG) void k_score_rows(
     double acc[1];
     int64_t i;
     bool valid;
-    sx_segwalk<1, CHUNK, NT>(tiles, tile, rowptr, colidx, val, StageDot{x}, lds, i, valid, acc);
+    double bi = 0.0, yi = 0.0;
+    auto pre = [&](int64_t seg, bool ok) {
+        if (ok) {
+            bi = b[seg];
+            if (flag) yi = y[seg];
+        }
+    };
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, rowptr, colidx, val, StageDot{x}, lds, i, valid, acc, pre);
     if (!valid) return;
-    const double sp = b[i] - acc[0];
+    const double sp = bi - acc[0];
     if (s_p) s_p[i] = sp;
-    if (flag) flag[i] = (sp < (gamma_dual * (-y[i]))) ? 1 : 0;
+    if (flag) flag[i] = (sp < (gamma_dual * (-yi))) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------- K10
@@ -348,6 +366,13 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     SX_REQUIRE(y && c, "y or c is NULL");
     SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
     if (A->n == 0) return SX_OK;
+    if (ctx->opt_window) { // opt-in LDS operand window; its per-tile table is built on first use
+        if (!A->csc_win_tried) {
+            A->csc_win_tried = 1;
+            SX_TRY(sx_window_setup(ctx, A->csc_tiles, A->n_csc_tiles, A->csc_ptr, A->csc_idx, A->m, &A->csc_win_lo));
+        }
+        if (A->csc_win_lo) return sx_window_score_columns(ctx, A, y, c, x, l, u, gamma, s_d, code);
+    }
     const unsigned grid = walk_grid(ctx, A->n_csc_tiles);
 #define SX_LAUNCH_K1(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_columns<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,        \

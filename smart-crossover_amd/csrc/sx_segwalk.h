@@ -64,18 +64,26 @@ __device__ __forceinline__ sx_v2d sx_ld_d2(const double *p) {
 // Stage functor:  void operator()(double value, int32_t index, double (&out)[NACC]) const
 // Walks tile `tile` (segments [tiles[tile], tiles[tile+1])).  On return acc[] holds the NACC
 // running sums of segment `seg` (valid lanes only).
-template <int NACC, int CHUNK, bool NT = false, class Stage>
+struct sx_no_prologue {
+    __device__ __forceinline__ void operator()(int64_t, bool) const {}
+};
+
+// `pre(seg, valid)` runs as soon as the lane knows its segment, before any entry is streamed: the
+// place to issue the loads an epilogue will need (c, x, l, u ...) so that their HBM latency overlaps
+// the walk instead of following it.
+template <int NACC, int CHUNK, bool NT = false, class Stage, class Pre = sx_no_prologue>
 __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, int64_t tile,
                                            const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx,
                                            const double *__restrict__ val, const Stage &stage,
                                            sx_walk_lds<NACC, CHUNK> &lds, int64_t &seg, bool &valid,
-                                           double (&acc)[NACC]) {
+                                           double (&acc)[NACC], const Pre &pre = Pre()) {
     const int tid = threadIdx.x;
     const int64_t s0 = tiles[tile];
     const int64_t s1 = tiles[tile + 1];
     seg = s0 + tid;
     valid = seg < s1;
+    pre(seg, valid);
     const int64_t p_lo = ptr[s0];
     const int64_t p_hi = ptr[s1];
     int64_t cs = p_hi, ce = p_hi;

@@ -25,10 +25,12 @@ def main():
     ap.add_argument("--structure", default="staircase")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--window", type=int, default=4096, help="staircase window W (rows) of the synthetic LP")
+    ap.add_argument("--variants", default="all", help="'all' or 'default' (swizzle on, nt off, chunk 4096 only)")
     args = ap.parse_args()
     m, nb, k = (1_000_000, 10_000_000, 8) if args.workload == "c5" else (20_000, 100_000, 20)
     structure = args.structure if args.workload == "c5" else "uniform"
-    sh = workloads.lp_shard(0, 1, m=m, n_block=nb, k=k, structure=structure)
+    sh = workloads.lp_shard(0, 1, m=m, n_block=nb, k=k, structure=structure, window=args.window)
     ctx = Context(0)
     dC, dR = ctx.column_shard(sh.col_block), ctx.row_shard(sh.row_block)
     d = {kk: ctx.to_device(getattr(sh, kk)) for kk in ("y", "x", "c", "l", "u", "b")}
@@ -37,7 +39,9 @@ def main():
     k1_bytes = 12 * sh.col_block.nnz + 49 * nb + 8 * m
     k2_bytes = 12 * sh.row_block.nnz + 8 * nb + 33 * m
 
-    variants = list(itertools.product((0, 1), (0, 1), (4096, 2048)))   # swizzle, nt, chunk
+    variants = list(itertools.product((0, 1), (0, 1), (4096, 2048), (0,)))   # swizzle, nt, chunk, lds-window
+    if args.variants == "default":
+        variants = [(1, 0, 4096, 0), (1, 0, 4096, 1)]
     res = {v: {"k1": [], "k2": []} for v in variants}
     ref = None
     for rnd in range(args.rounds):
@@ -45,6 +49,7 @@ def main():
             ctx.set_option("xcd_swizzle", v[0])
             ctx.set_option("nt_stream", v[1])
             ctx.set_option("chunk", v[2])
+            ctx.set_option("window", v[3])
             ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)   # warm
             ctx.marker(0)
             for _ in range(args.reps):
@@ -60,11 +65,11 @@ def main():
                 if ref is None:
                     ref = got
                 assert got == ref, f"variant {v} changed the results"
-    print(f"workload {args.workload}/{structure}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
-    print("swz nt chunk |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med)")
+    print(f"workload {args.workload}/{structure} window={args.window}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
+    print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med)")
     for v in variants:
         a, b = np.array(res[v]["k1"]), np.array(res[v]["k2"])
-        print(f" {v[0]}  {v[1]}  {v[2]:4d} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
+        print(f" {v[0]}  {v[1]}  {v[2]:4d}  {v[3]} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
               f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f}")
 
 
