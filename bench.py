@@ -50,6 +50,46 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def crossover_host_path(cpu_budget_s: float):
+    """Crossover wall-time of the part this repository accelerates: one ``get_perturb_problem`` call
+    (reference lp_methods/algorithms.py:79-111 -- scoring, index sets, projector CG, perturbed cost,
+    sub-problem) on BASELINE config 2 (2e4 x 1e5, 2e6 nnz) from an interior point in host memory to
+    the restricted LP in host memory, through the drop-in Python API (uploads and downloads included).
+    The LP re-solves that follow are third-party solver time on both sides and are not part of it.
+    CPU side: the numpy/scipy oracle with the matrix-free CG -- faster than the reference's own
+    explicit Y*Y^T path (55.8 s measured in SURVEY.md section 6), so the ratio is conservative."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods.algorithms import get_perturb_problem
+    inst = workloads.config2()
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    times = []
+    mgr = None
+    for _ in range(3):                      # first call uploads the matrix; report the steady state too
+        t0 = time.perf_counter()
+        with redirect_stdout(io.StringIO()):
+            mgr = get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+        times.append((time.perf_counter() - t0) * 1e3)
+    from oracle import lp_path as L         # checker / baseline only
+    t0 = time.perf_counter()
+    res = L.scoring_pass(inst.A, inst.b, inst.c, inst.l, inst.u, inst.x, inst.y)
+    c_pt, info = L.perturbed_cost_full(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense, inst.x, False, explicit=False)
+    sub = L.sub_problem(inst.A, inst.b, c_pt, inst.l, inst.u, inst.sense, res["fix_low"], res["fix_up"], res["fixed_rows"])
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    same = (np.array_equal(mgr.var_info["fix_low"], res["fix_low"]) and np.array_equal(mgr.var_info["fix_up"], res["fix_up"])
+            and np.array_equal(mgr.fixed_constraints, res["fixed_rows"])
+            and np.array_equal(mgr.lp_sub.A.indices, sub["A"].indices) and np.array_equal(mgr.lp_sub.b, sub["b"]))
+    if not same:
+        raise SystemExit("bench: device get_perturb_problem disagrees with the CPU oracle")
+    return {"workload": "c2: 2e4 x 1e5, 2e6 nnz, get_perturb_problem (is_feas=False), host memory to host memory",
+            "gpu_ms_first_call": times[0], "gpu_ms": float(np.median(times[1:])), "cpu_ms": cpu_ms, "cpu_cores": 1,
+            "cpu_kind": "port (matrix-free CG; the reference's explicit YY^T path took 55.8 s in SURVEY.md)",
+            "speedup": cpu_ms / float(np.median(times[1:])), "cg_iters": int(mgr.perturb_info["cg_iters"]),
+            "fixed_columns": int(mgr.get_num_fixed_variables()), "fixed_rows": int(mgr.get_num_fixed_constraints()),
+            "index_sets_and_subproblem_match_cpu": True}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +100,7 @@ def main():
                     help="row structure of the synthetic LP (default: staircase = netlib-style for c5, uniform for c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--no-crossover", action="store_true", help="skip the config-2 crossover host-path timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,6 +280,10 @@ def main():
                          f"numpy/scipy oracle, {spent / reps * 1e3:.0f} ms each; parity with the GPU pass checked",
                "ms_per_step": spent / reps * 1e3}
 
+    crossover = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_crossover:
+        crossover = crossover_host_path(args.cpu_seconds)
+
     if rank == 0:
         out = {
             "metric": "columns_scored_per_sec", "value": value, "unit": "columns/s", "n_gpus": world,
@@ -253,6 +298,7 @@ def main():
                          "algorithmic_bytes": int(k1_bytes), "avg_kernel_ms": k1_avg_s * 1e3,
                          "min_kernel_ms": float(np.min(k1_ms))},
             "cpu_baseline": cpu,
+            "crossover": crossover,
             "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),
                        "min_rc": mn, "argmin": am, "n_violating": bad},
             "device": dev_name,

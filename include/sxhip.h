@@ -63,7 +63,8 @@ int sx_ctx_destroy(sx_ctx *ctx);
 int sx_ctx_sync(sx_ctx *ctx);
 /* Tuning knobs (performance only, never results): "xcd_swizzle" 0/1 (default 1), "nt_stream" 0/1
  * (default 0), "chunk" 2048/4096 (default 4096), "window" 0/1 (default 0: per-tile LDS operand window
- * in K1).  Unknown keys return SX_ERR_INVALID. */
+ * in K1), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch).  Unknown keys return
+ * SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
 int sx_ctx_device_info(sx_ctx *ctx, char *name, size_t name_len, int *cu_count, uint64_t *hbm_bytes);

@@ -287,7 +287,10 @@ SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, c
     const int swzT = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
     const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64) ? 1 : 0;
     const int gT = grid_for(ctx, A->n_csc_tiles), gA = grid_for(ctx, A->n_csr_tiles);
-    const int gv = 1024; // vector kernels: grid-stride, 1024 partials
+    // vector kernels: grid-stride with ~4 elements per lane, at most 1024 workgroups (= partials); a
+    // grid sized for the larger of m and n keeps small problems from launching mostly idle blocks
+    int64_t gv64 = ((m > n ? m : n) + 4 * SX_WG - 1) / (4 * SX_WG);
+    const int gv = static_cast<int>(gv64 < 1 ? 1 : (gv64 > 1024 ? 1024 : gv64));
 
     // workspace: state | partial_pq[CG_GRID] | partial_rr[CG_GRID] | z r p q [m] | w atz [n]
     const size_t off_state = 0;
@@ -322,24 +325,55 @@ SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, c
     int launched = 0;
     bool finished = trivial;
     if (!trivial && !(bnrm < tol * bnrm)) { // scipy tests ||r|| < atol before the first iteration too
-        const int batch = 25;
-        while (launched < maxiter && !finished) {
-            const int upto = (launched + batch < maxiter) ? launched + batch : maxiter;
-            for (; launched < upto; ++launched) {
-                const int par = launched & 1;
-                hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles,
-                                   swzT, A->csc_ptr, A->csc_idx, A->csc_val, p, xa, w);
-                hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles,
-                                   swzA, A->csr_ptr, A->csr_idx, A->csr_val, w, xs, p, q, ppq);
-                hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, gA, p, q,
-                                   z, r, prr);
-                hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(SX_WG), 0, s, st, par, m, prr, gv, r, p);
+        auto enqueue_iteration = [&](int par) {
+            hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
+                               A->csc_ptr, A->csc_idx, A->csc_val, p, xa, w);
+            hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
+                               A->csr_ptr, A->csr_idx, A->csr_val, w, xs, p, q, ppq);
+            hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, gA, p, q, z, r, prr);
+            hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(SX_WG), 0, s, st, par, m, prr, gv, r, p);
+        };
+        // the loop is launch-bound on cache-resident problems (four ~4 us kernels per iteration): a
+        // batch of 24 iterations (even, so the rho parity repeats) is captured once into a hipGraph and
+        // replayed; the host polls the done flag between batches.  Direct launches serve the tail and
+        // are the fallback when capture is unavailable.
+        const int batch = 24;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (ctx->opt_graph && maxiter >= 2 * batch) {
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                for (int k = 0; k < batch; ++k) enqueue_iteration(k & 1);
+                if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                    exec = nullptr;
             }
-            SX_HIP(hipGetLastError());
-            SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
-            SX_HIP(hipStreamSynchronize(s));
+            (void)hipGetLastError();
+        }
+        int rc_loop = SX_OK;
+        while (launched < maxiter && !finished) {
+            if (exec && launched + batch <= maxiter) {
+                if (hipGraphLaunch(exec, s) != hipSuccess) {
+                    sx_set_error("hipGraphLaunch failed in the CG loop");
+                    rc_loop = SX_ERR_HIP;
+                    break;
+                }
+                launched += batch;
+            } else {
+                const int upto = (launched + batch < maxiter) ? launched + batch : maxiter;
+                for (; launched < upto; ++launched) enqueue_iteration(launched & 1);
+            }
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                sx_set_error("CG iteration batch failed");
+                rc_loop = SX_ERR_HIP;
+                break;
+            }
             finished = host.done != 0;
         }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc_loop != SX_OK) return rc_loop;
     }
     SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));

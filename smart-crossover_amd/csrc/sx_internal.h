@@ -64,6 +64,7 @@ struct sx_ctx {
     int opt_nt_stream = 0;   // non-temporal loads for the streamed entry arrays
     int opt_chunk = 4096;    // staged entries per chunk (2048 or 4096)
     int opt_window = 0;      // 1: per-tile LDS operand window in K1 (opt-in, see sx_window.hip)
+    int opt_graph = 1;       // replay the CG iteration batch as a hipGraph
 };
 
 int sx_reserve(sx_ctx *ctx, size_t bytes); // ensure ctx->ws holds >= bytes

@@ -8,16 +8,25 @@
 namespace {
 
 __global__ __launch_bounds__(SX_WG) void k_tile_flags(const int64_t *__restrict__ ptr, int64_t nseg,
-                                                      uint8_t *__restrict__ flag) {
+                                                      int64_t budget, uint8_t *__restrict__ flag) {
     const int64_t s = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
     if (s >= nseg) return;
     const int64_t sb = s - (s % SX_WG);
     bool cut = (s == sb);
     if (!cut) {
         const int64_t origin = ptr[sb];
-        cut = ((ptr[s] - origin) / SX_TILE_BUDGET) != ((ptr[s - 1] - origin) / SX_TILE_BUDGET);
+        cut = ((ptr[s] - origin) / budget) != ((ptr[s - 1] - origin) / budget);
     }
     flag[s] = cut ? 1 : 0;
+}
+
+// Entry budget of a tile: SX_TILE_BUDGET for large matrices; halved (down to 1024) while the matrix
+// would otherwise yield fewer than ~2048 tiles, so that cache-resident problems still put several
+// workgroups on each of the 256 CUs (config 2: 250 row tiles -> 2000).
+inline int64_t tile_budget(int64_t nnz) {
+    int64_t budget = SX_TILE_BUDGET;
+    while (budget > 1024 && nnz / budget < 2048) budget >>= 1;
+    return budget;
 }
 
 } // namespace
@@ -43,10 +52,16 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
         sx_set_error("hipMalloc failed while building tiles: %s", hipGetErrorString(e));
         rc = SX_ERR_NOMEM;
     }
-    int64_t nt = 0;
+    int64_t nt = 0, nnz = 0;
+    if (rc == SX_OK &&
+        (hipMemcpyAsync(&nnz, ptr_dev + nseg, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+         hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        sx_set_error("nnz download failed while building tiles");
+        rc = SX_ERR_HIP;
+    }
     if (rc == SX_OK) {
         const unsigned nb = static_cast<unsigned>((nseg + SX_WG - 1) / SX_WG);
-        hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(SX_WG), 0, ctx->stream, ptr_dev, nseg, flag);
+        hipLaunchKernelGGL(k_tile_flags, dim3(nb), dim3(SX_WG), 0, ctx->stream, ptr_dev, nseg, tile_budget(nnz), flag);
         rc = sx_select_indices_dev(ctx, nseg, flag, 1, idx, count);
     }
     if (rc == SX_OK) {

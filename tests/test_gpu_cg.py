@@ -76,6 +76,23 @@ def test_projector_trivial_and_maxiter(ctx):
     assert res.proj_norm == pytest.approx(float(np.linalg.norm(proj)), rel=1e-9)
 
 
+def test_projector_graph_replay_equals_direct_launches(ctx):
+    """The hipGraph replay of the iteration batch is an execution detail: same kernels, same order,
+    hence bit-identical results and iteration counts."""
+    inst = workloads.sparse_lp(300, 1500, 6, seed=12, stratified=False)
+    xr = np.maximum(L.x_perturb_val(inst.x, inst.l, inst.u), 1e-2)
+    out = {}
+    for flag in (0, 1):
+        ctx.set_option("graph", flag)
+        for maxiter in (1000, 50, 7):          # 50: two graph batches + 2 direct; 7: direct only
+            r = device_projector(ctx, inst.A, inst.b, inst.c, inst.sense, xr, maxiter=maxiter)
+            out[(flag, maxiter)] = (r.proj_norm, int(r.iters), int(r.converged), r.rel_residual)
+    ctx.set_option("graph", 1)
+    for maxiter in (1000, 50, 7):
+        assert out[(0, maxiter)] == out[(1, maxiter)], maxiter
+    assert out[(1, 50)][1] == 50 and out[(1, 7)][1] == 7 and out[(1, 1000)][2] == 1
+
+
 def test_projector_config2_size_hits_cap(ctx, capsys):
     """Config 2 (2e4 x 1e5): the reference's CG runs into maxiter=1000 here and its
     result then depends on rounding order; the device must finish, report 1000 iterations and land
