@@ -1,0 +1,117 @@
+"""GPU: BASELINE.json's full-size configurations, checked through size-independent properties and
+sampled bit-exact comparisons (the oracle finishes these sizes in seconds, so most checks are exact).
+
+  c4  MCF 2^17 nodes x 2^20 arcs      indicators, ranking, pricing
+  c5  LP  1e6 rows x 1e7 columns      scoring pass: sampled exact sums, cross-kernel identities,
+                                      determinism, index-set invariants
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from oracle import lp_path as L
+from oracle import net_path as N
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from smart_crossover.hip import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_config4_mcf_indicators_ranking_pricing(ctx):
+    inst = workloads.config4()
+    V, E = inst.A.shape
+    assert (V, E) == (2 ** 17, 2 ** 20)
+    dA = ctx.matrix(inst.A)
+    ind = ctx.empty(E, np.float64)
+    ctx.flow_indicator_mcf(dA, ctx.to_device(inst.x), ctx.to_device(inst.u), ind)
+    got = ind.download()
+    want, _ = N.mcf_flow_indicators(inst.A, inst.x, inst.u)
+    assert bits_equal(got, want)
+    q = ctx.argsort_desc(ind).download()
+    # sortedness + permutation + the tie rule, without a second full sort on the host
+    key = got[q]
+    assert np.all(key[:-1] >= key[1:])
+    assert np.array_equal(np.sort(q), np.arange(E))
+    ties = key[:-1] == key[1:]
+    assert np.all(q[:-1][ties] > q[1:][ties])
+    assert np.array_equal(q, N.rank_desc(got))
+    # pricing on the incidence matrix with random potentials
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(V)
+    vb = rng.integers(-2, 1, E).astype(np.int8)
+    rc = ctx.empty(E, np.float64)
+    res = ctx.price(dA, ctx.to_device(y), ctx.to_device(inst.c), ctx.to_device(vb), 1e-6, rc)
+    want_rc = N.mcf_reduced_cost(inst.A, inst.c, y, vb.astype(int))
+    assert bits_equal(rc.download(), want_rc)
+    mn, am, bad = ctx.read_price(res)
+    assert mn == want_rc.min() and am == int(np.flatnonzero(want_rc == want_rc.min())[0])
+    assert bad == int(np.count_nonzero(~(want_rc >= -1e-6)))
+    dA.free()
+
+
+def test_config5_scoring_pass_properties(ctx):
+    sh = workloads.lp_shard(0, 1)                       # 1e6 x 1e7, 8e7 nnz, netlib-style structure
+    m, n = sh.m, sh.n_block
+    dC, dR = ctx.column_shard(sh.col_block), ctx.row_shard(sh.row_block)
+    d = {k: ctx.to_device(getattr(sh, k)) for k in ("y", "x", "c", "l", "u", "b")}
+    s_d, code = ctx.empty(n, np.float64), ctx.empty(n, np.uint8)
+    s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
+    gamma = 1e-3
+
+    def run():
+        ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], gamma, s_d, code)
+        ctx.score_rows(dR, d["x"], d["b"], d["y"], gamma, s_p, flag)
+        return s_d.download(), code.download(), s_p.download(), flag.download()
+
+    sd1, cd1, sp1, fl1 = run()
+    sd2, cd2, sp2, fl2 = run()
+    # determinism: no atomics, fixed orders -> bitwise identical on every launch
+    assert sd1.tobytes() == sd2.tobytes() and sp1.tobytes() == sp2.tobytes()
+    assert np.array_equal(cd1, cd2) and np.array_equal(fl1, fl2)
+
+    # sampled exactness: explicit left-to-right sums for 5000 random columns and 2000 random rows
+    rng = np.random.default_rng(7)
+    cols = np.sort(rng.choice(n, 5000, replace=False))
+    C = sh.col_block
+    for j in cols[:500]:
+        lo, hi = C.indptr[j], C.indptr[j + 1]
+        acc = np.float64(0.0)
+        for k in range(lo, hi):
+            acc = acc + np.float64(C.data[k]) * np.float64(sh.y[C.indices[k]])
+        assert sd1[j] == sh.c[j] - acc
+    sub = C[:, cols]
+    assert bits_equal(sd1[cols], sh.c[cols] - sub.T @ sh.y)              # scipy on the sampled columns
+    rows = np.sort(rng.choice(m, 2000, replace=False))
+    assert bits_equal(sp1[rows], sh.b[rows] - sh.row_block[rows] @ sh.x)
+
+    # the flags are pure functions of the slacks
+    assert np.array_equal(cd1, L.column_codes(sh.x[:n], sh.l, sh.u, sd1, gamma))
+    assert np.array_equal(fl1, L.row_flags(sp1, sh.y, gamma))
+
+    # cross-kernel identity: pricing without basis flips reproduces s_d bit for bit
+    rc = ctx.empty(n, np.float64)
+    res = ctx.price(dC, d["y"], d["c"], None, 1e-6, rc)
+    assert rc.download().tobytes() == sd1.tobytes()
+    mn, am, bad = ctx.read_price(res)
+    assert mn == sd1.min() and am == int(np.argmin(sd1)) and bad == int(np.count_nonzero(~(sd1 >= -1e-6)))
+
+    # index sets: ascending, complete, consistent with the codes
+    low, up, fr = ctx.where(code, 1), ctx.where(code, 2), ctx.where(flag)
+    for idx, mask in ((low, (cd1 & 1) != 0), (up, (cd1 & 2) != 0), (fr, fl1 != 0)):
+        assert idx.dtype == np.int64 and np.all(np.diff(idx) > 0) and idx.size == int(mask.sum())
+        assert mask[idx].all()
+    assert low.size > n // 2 and up.size > 0 and fr.size > 0
+
+    # a checksum of checksums against an independent float128-free bound: sum(s_d) = sum(c) - y.(A 1)
+    lhs = float(np.sum(sd1))
+    rhs = float(np.sum(sh.c) - sh.y @ (C @ np.ones(n)))
+    assert abs(lhs - rhs) <= 1e-9 * (abs(rhs) + np.sum(np.abs(sd1)))
+    dC.free()
+    dR.free()
