@@ -266,6 +266,29 @@ int sx_mask_f64_dev(sx_ctx *ctx, int64_t n, const double *src, const uint8_t *ma
 int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                       const double *c, double tol, int maxiter, sx_cg_result *result);
 
+/* ------------------------------------------------------------------ K16: device simplex
+ * replaces the third-party re-solves behind the SolverCaller seam for the simplex family
+ * (solver_caller/solving.py:32-68; call sites lp_methods/algorithms.py:69-74 and
+ * network_methods/net_manager.py:222,468):
+ *     min c^T x   s.t.  (A x)_i = b_i  (row_is_lt[i] == 0)  or  <= b_i  (== 1),   l <= x <= u
+ * Bounded revised primal simplex, two phases, explicit dense basis inverse in HBM (m <= 16384, else
+ * SX_ERR_UNSUPPORTED), Dantzig pricing with Bland fallback.  vbasis_in[n] / cbasis_in[m] (both or
+ * neither; Gurobi codes 0 basic, -1 lower, -2 upper, -3 free / 0 basic, -1 non-basic) give a warm
+ * start; a singular or primal-infeasible warm basis is dropped.  Outputs (device, any may be NULL):
+ * x[n], y[m] with reduced cost = c - A^T y, vbasis[n], cbasis[m].  Blocking.  All arrays device. */
+typedef struct sx_simplex_result {
+    int64_t status;          /* 0 optimal, 1 infeasible, 2 unbounded, 3 iteration limit, 4 numerical trouble */
+    int64_t iters;           /* pivots and bound flips, both phases */
+    int64_t phase1_iters;
+    int64_t warm_start_used; /* 1 when the given basis was installed and primal feasible */
+    double obj;              /* c^T x */
+    double max_violation;    /* largest bound violation of a basic variable at exit */
+} sx_simplex_result;
+int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                         const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
+                         const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
+                         double *x, double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,15 @@ class Context:
                                             int(maxiter), _ptr(proj_cols), _ptr(proj_rows), C.byref(res)))
         return res
 
+    def simplex(self, A, b, c, l, u, row_is_lt, vbasis=None, cbasis=None, max_iter=0, feas_tol=1e-7, opt_tol=1e-7,
+                x=None, y=None, vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
+        """K16 (blocking): bounded primal simplex on the device; device pointers in and out."""
+        res = _l.SimplexResult()
+        _l.check(self._lib.sx_simplex_solve_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt),
+                                                _ptr(vbasis), _ptr(cbasis), int(max_iter), float(feas_tol), float(opt_tol),
+                                                _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+        return res
+
     def x_real(self, n, x, l, u, out, apply_floor: bool = True) -> None:
         _l.check(self._lib.sx_x_real_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), int(bool(apply_floor)),
                                          _ptr(out)))

@@ -40,6 +40,11 @@ class CgResult(C.Structure):
                 ("iters", C.c_int64), ("converged", C.c_int64)]
 
 
+class SimplexResult(C.Structure):
+    _fields_ = [("status", C.c_int64), ("iters", C.c_int64), ("phase1_iters", C.c_int64),
+                ("warm_start_used", C.c_int64), ("obj", C.c_double), ("max_violation", C.c_double)]
+
+
 _vp = C.c_void_p
 _i64 = C.c_int64
 _dbl = C.c_double
@@ -95,6 +100,8 @@ PROTOTYPES = {
     "sx_x_real_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "sx_mask_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
+    "sx_simplex_solve_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                    C.POINTER(SimplexResult)]),
     "sx_projector_norm": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
 }
 

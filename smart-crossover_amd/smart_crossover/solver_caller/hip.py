@@ -1,0 +1,205 @@
+"""``HipCaller``: the device simplex of libsxhip.so (kernel group K16) behind the ``SolverCaller``
+seam -- ``solver="HIP"`` in ``solve_lp`` / ``solve_mcf`` / ``solve_ot`` / ``network_crossover``.
+
+It serves the *simplex family* of methods ('default', 'simplex', 'primal_simplex', 'dual_simplex',
+'network_simplex' all run the bounded primal simplex) with Gurobi-style warm bases, i.e. the
+re-solves the crossover algorithms issue with a warm start (lp_methods/algorithms.py:69-74,
+network_methods/net_manager.py:222,468).  It has no interior-point method: 'barrier' raises
+NotImplementedError -- pair it with a barrier-capable backend through the composite name
+``"<barrier backend>+HIP"`` (e.g. ``"HGS+HIP"``): barrier runs go to the first backend, simplex runs
+to the device.  Size limit: 16384 rows (dense basis inverse in HBM).
+"""
+from __future__ import annotations
+
+import datetime
+import time
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from smart_crossover.formats import GeneralLP, StandardLP
+from smart_crossover.output import Basis
+from smart_crossover.solver_caller.caller import SolverCaller, SolverSettings
+
+_STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
+
+
+class HipCaller(SolverCaller):
+    solver_name = "HIP"
+
+    def __init__(self, solver_settings: Optional[SolverSettings] = None) -> None:
+        super().__init__(solver_settings)
+        self._warm: Optional[Basis] = None
+        self._res = None
+        self._runtime = 0.0
+        self._x = self._y = self._vb = self._cb = None
+
+    # -- loading -------------------------------------------------------------------------------
+    def _load(self, A, b, c, l, u, row_lt) -> None:
+        self._A = sp.csr_matrix(A)
+        self._b, self._c = np.asarray(b, float), np.asarray(c, float)
+        self._l, self._u = np.asarray(l, float), np.asarray(u, float)
+        self._row_lt = np.asarray(row_lt, dtype=np.uint8)
+        self._warm = None
+        self._res = None
+
+    def read_genlp(self, genlp: GeneralLP) -> None:
+        self._load(genlp.A, genlp.b, genlp.c, genlp.l, genlp.u, np.asarray(genlp.sense) == "<")
+        self._resident = getattr(genlp, "_sx_resident", None)
+
+    def read_stdlp(self, stdlp: StandardLP) -> None:
+        self._load(stdlp.A, stdlp.b, stdlp.c, stdlp.l, stdlp.u, np.zeros(np.asarray(stdlp.b).size, dtype=bool))
+        self._resident = None
+
+    def get_A(self) -> sp.csr_matrix:
+        return self._A
+
+    def get_b(self) -> np.ndarray:
+        return self._b
+
+    def get_sense(self) -> np.ndarray:
+        return np.where(self._row_lt.astype(bool), "<", "=")
+
+    def get_c(self) -> np.ndarray:
+        return self._c
+
+    def get_l(self) -> np.ndarray:
+        return self._l
+
+    def get_u(self) -> np.ndarray:
+        return self._u
+
+    # -- warm starts ---------------------------------------------------------------------------
+    def add_warm_start_basis(self, basis: Basis) -> None:
+        self._warm = basis
+
+    def add_warm_start_solution(self, start_solution: Tuple[np.ndarray, np.ndarray]) -> None:
+        pass                                    # a primal simplex starts from a basis, not from a point
+
+    # -- runs ----------------------------------------------------------------------------------
+    def _solve(self) -> None:
+        from smart_crossover.hip.device import default_context
+        ctx = default_context()
+        m, n = self._A.shape
+        res = getattr(self, "_resident", None)
+        dA = res.A if res is not None and res.A.shape == (m, n) and res.A.handle is not None else ctx.matrix(self._A)
+        own = res is None or dA is not res.A
+        put = lambda v: ctx.to_device(np.ascontiguousarray(v, dtype=np.float64))   # noqa: E731
+        d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+        d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
+        vb_in = cb_in = None
+        if self._warm is not None and self._warm.vbasis.size == n and self._warm.cbasis.size == m:
+            vb_in = ctx.to_device(np.clip(self._warm.vbasis, -3, 0).astype(np.int8))
+            cb_in = ctx.to_device(np.clip(self._warm.cbasis, -1, 0).astype(np.int8))
+        t0 = time.perf_counter()
+        self._res = ctx.simplex(dA, put(self._b), put(self._c), put(self._l), put(self._u), ctx.to_device(self._row_lt),
+                                vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
+        self._runtime = time.perf_counter() - t0
+        self._x, self._y = d_x.download(), d_y.download()
+        self._vb, self._cb = d_vb.download().astype(int), d_cb.download().astype(int)
+        if own:
+            dA.free()
+
+    def run_default(self) -> None:
+        self._solve()
+
+    run_simplex = run_primal_simplex = run_dual_simplex = run_network_simplex = run_default
+
+    def run_barrier(self) -> None:
+        raise NotImplementedError("the HIP backend has no interior-point method; use e.g. solver='HGS+HIP'")
+
+    run_barrier_no_crossover = run_barrier
+
+    def reset_model(self) -> None:
+        self._res = None
+        self._warm = None
+
+    # -- results -------------------------------------------------------------------------------
+    def return_status(self) -> str:
+        return _STATUS.get(int(self._res.status), "UNKNOWN") if self._res is not None else "UNKNOWN"
+
+    def return_x(self) -> np.ndarray:
+        assert self.return_status() == "OPTIMAL", "The model is not solved to optimal!"
+        return self._x
+
+    def return_y(self) -> np.ndarray:
+        return self._y
+
+    def return_barx(self) -> Optional[np.ndarray]:
+        return None
+
+    def return_obj_val(self) -> float:
+        return float(self._res.obj)
+
+    def return_runtime(self) -> datetime.timedelta:
+        return datetime.timedelta(seconds=self._runtime)
+
+    def return_iter_count(self) -> int:
+        return int(self._res.iters)
+
+    def return_bar_iter_count(self) -> int:
+        return 0
+
+    def return_reduced_cost(self) -> np.ndarray:
+        return self._c - self._A.T @ self._y
+
+    def return_basis(self) -> Optional[Basis]:
+        return Basis(self._vb, self._cb)
+
+
+class SplitCaller(SolverCaller):
+    """``"<barrier backend>+<simplex backend>"``: barrier runs on the first, everything else on the second."""
+
+    def __init__(self, bar: SolverCaller, spx: SolverCaller, name: str) -> None:
+        super().__init__(bar.settings)
+        self.solver_name = name
+        self._bar, self._spx = bar, spx
+        self._active = spx
+
+    def read_genlp(self, genlp):
+        self._bar.read_genlp(genlp)
+        self._spx.read_genlp(genlp)
+
+    def read_stdlp(self, stdlp):
+        self._bar.read_stdlp(stdlp)
+        self._spx.read_stdlp(stdlp)
+
+    def add_warm_start_basis(self, basis):
+        self._spx.add_warm_start_basis(basis)
+
+    def add_warm_start_solution(self, start_solution):
+        self._spx.add_warm_start_solution(start_solution)
+
+    def run_barrier(self):
+        self._active = self._bar
+        self._bar.run_barrier()
+
+    def run_barrier_no_crossover(self):
+        self._active = self._bar
+        self._bar.run_barrier_no_crossover()
+
+    def _spx_run(self, name):
+        self._active = self._spx
+        getattr(self._spx, name)()
+
+    def run_default(self):
+        self._spx_run("run_default")
+
+    def run_simplex(self):
+        self._spx_run("run_simplex")
+
+    def run_primal_simplex(self):
+        self._spx_run("run_primal_simplex")
+
+    def run_dual_simplex(self):
+        self._spx_run("run_dual_simplex")
+
+    def run_network_simplex(self):
+        self._spx_run("run_network_simplex")
+
+    def return_output(self):
+        return self._active.return_output()
+
+    def return_status(self):
+        return self._active.return_status()

@@ -30,13 +30,23 @@ def _highs(settings: SolverSettings) -> SolverCaller:
     return HgsCaller(settings)
 
 
+def _hip(settings: SolverSettings) -> SolverCaller:
+    from smart_crossover.solver_caller.hip import HipCaller
+    return HipCaller(settings)
+
+
 register_backend("HGS", _highs)
+register_backend("HIP", _hip)
 
 
 def generate_solver_caller(solver: str = "GRB", solver_settings: Optional[SolverSettings] = None) -> SolverCaller:
     settings = solver_settings if solver_settings is not None else SolverSettings()
     if solver in _BACKENDS:
         return _BACKENDS[solver](settings)
+    if "+" in solver:      # "<barrier backend>+<simplex backend>", e.g. "HGS+HIP"
+        bar_name, spx_name = solver.split("+", 1)
+        from smart_crossover.solver_caller.hip import SplitCaller
+        return SplitCaller(generate_solver_caller(bar_name, settings), generate_solver_caller(spx_name, settings), solver)
     if solver in ("GRB", "CPL", "MSK"):
         package = {"GRB": "gurobipy", "CPL": "cplex", "MSK": "mosek"}[solver]
         raise ImportError(f"solver '{solver}' needs the commercial package '{package}', which is not part of this "

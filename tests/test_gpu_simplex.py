@@ -1,0 +1,162 @@
+"""GPU: K16, the device simplex behind solver="HIP".  Solver-chosen bases are not comparable across
+solvers, so the checks are solver-independent certificates: objective equal to an independent HiGHS
+solve, primal feasibility, dual feasibility by basis status, complementary basis size."""
+import io
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def settings():
+    from smart_crossover.solver_caller.caller import SolverSettings
+    return SolverSettings(log_console=0)
+
+
+def check_vertex(lp, out, want_obj, tol=1e-6):
+    x, y, basis = out.x, out.y, out.basis
+    assert out.status == "OPTIMAL"
+    assert out.obj_val == pytest.approx(want_obj, rel=1e-7, abs=1e-7)
+    assert float(lp.c @ x) == pytest.approx(want_obj, rel=1e-7, abs=1e-7)
+    s_p = lp.b - lp.A @ x
+    lt = np.asarray(lp.sense) == "<"
+    assert np.all(np.abs(s_p[~lt]) <= tol) and np.all(s_p[lt] >= -tol)
+    assert np.all(x >= lp.l - tol) and np.all(x <= lp.u + tol)
+    rc = lp.c - lp.A.T @ y
+    vb, cb = basis.vbasis, basis.cbasis
+    assert np.all(rc[vb == -1] >= -tol) and np.all(rc[vb == -2] <= tol) and np.all(np.abs(rc[vb == -3]) <= tol)
+    assert np.all(np.abs(rc[vb == 0]) <= tol)
+    assert np.all(y[lt & (cb == -1)] <= tol)                         # a tight '<' row has a non-positive dual
+    assert np.all(np.abs(y[cb == 0]) <= tol)                         # basic slack: zero dual
+    assert int(np.count_nonzero(vb == 0) + np.count_nonzero(cb == 0)) == lp.b.size
+
+
+def general_lp(inst):
+    from smart_crossover.formats import GeneralLP
+    return GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+
+
+@pytest.mark.parametrize("m,n,k,seed", [(27, 51, 2, 2024), (60, 150, 4, 1), (200, 700, 5, 2), (400, 1600, 5, 77)])
+def test_cold_start_matches_highs(m, n, k, seed):
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.config1() if (m, n) == (27, 51) else workloads.sparse_lp(m, n, k, seed=seed, stratified=False, frac_upper=0.4)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    assert ref.status == "OPTIMAL"
+    out = solve_lp(lp, "HIP", "primal_simplex", settings())
+    check_vertex(lp, out, ref.obj_val)
+    assert out.iter_count > 0
+
+
+def test_warm_start_from_optimal_basis_needs_no_pivot():
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(120, 400, 4, seed=5, stratified=False, frac_upper=0.4)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    out = solve_lp(lp, "HIP", "primal_simplex", settings(), warm_start_basis=ref.basis)
+    check_vertex(lp, out, ref.obj_val)
+    assert out.iter_count == 0
+    # a warm start from the HIP solver's own basis is a fixed point too
+    again = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=out.basis)
+    assert again.iter_count == 0 and np.array_equal(again.basis.vbasis, out.basis.vbasis)
+    # a garbage basis is dropped, not trusted
+    from smart_crossover.output import Basis
+    junk = Basis(np.zeros(lp.c.size), -np.ones(lp.b.size))
+    out2 = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=junk)
+    check_vertex(lp, out2, ref.obj_val)
+
+
+def test_free_variables_upper_bounds_and_inequalities():
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.solver_caller.solving import solve_lp
+    rng = np.random.default_rng(3)
+    m, n = 40, 90
+    A = sp.random(m, n, density=0.15, random_state=4, format="csr")
+    A.data = rng.uniform(-1, 1, A.nnz)
+    x0 = rng.uniform(-1, 1, n)
+    l = np.where(rng.random(n) < 0.3, -np.inf, x0 - rng.random(n))
+    u = np.where(rng.random(n) < 0.3, np.inf, x0 + rng.random(n))
+    free = rng.random(n) < 0.1
+    l[free], u[free] = -np.inf, np.inf
+    sense = np.where(rng.random(m) < 0.5, "<", "=")
+    b = A @ x0 + np.where(sense == "<", rng.random(m), 0.0)
+    y0 = rng.standard_normal(m)
+    y0[sense == "<"] = -np.abs(y0[sense == "<"])
+    c = A.T @ y0 + rng.standard_normal(n) * 0.1 * (~free)          # bounded below: dual feasible up to a small slack
+    lp = GeneralLP(A, b, c, l, u, sense)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    if ref.status != "OPTIMAL":
+        pytest.skip("generated LP is not bounded")
+    out = solve_lp(lp, "HIP", "default", settings())
+    check_vertex(lp, out, ref.obj_val)
+
+
+def test_infeasible_and_unbounded():
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.solver_caller.solving import solve_lp
+    bad = GeneralLP(sp.csr_matrix(np.array([[1.0, 1.0], [1.0, 1.0]])), np.array([1.0, 3.0]), np.ones(2), np.zeros(2),
+                    np.full(2, np.inf), np.array(["=", "="]))
+    out = solve_lp(bad, "HIP", "default", settings())
+    assert out.status == "INFEASIBLE" and out.x is None
+    unb = GeneralLP(sp.csr_matrix(np.array([[1.0, -1.0]])), np.array([1.0]), np.array([-1.0, -1.0]), np.zeros(2),
+                    np.full(2, np.inf), np.array(["<"]))
+    out = solve_lp(unb, "HIP", "default", settings())
+    assert out.status == "UNBOUNDED"
+    with pytest.raises(NotImplementedError):
+        solve_lp(bad, "HIP", "barrier", settings())
+
+
+def test_mcf_and_degenerate_assignment():
+    from smart_crossover.formats import MinCostFlow, OptTransport
+    from smart_crossover.solver_caller.solving import solve_mcf, solve_ot
+    mi = workloads.mcf(60, 400, seed=9)
+    mcf = MinCostFlow(A=mi.A, b=mi.b, c=mi.c, u=mi.u)
+    ref = solve_mcf(mcf, "HGS", "default", settings())
+    out = solve_mcf(mcf, "HIP", "network_simplex", settings())
+    assert out.status == "OPTIMAL" and out.obj_val == pytest.approx(ref.obj_val, rel=1e-8)
+    assert np.allclose(mi.A @ out.x, mi.b, atol=1e-6) and np.all(out.x >= -1e-7) and np.all(out.x <= mi.u + 1e-7)
+    # assignment problem: every vertex is highly degenerate (tests the Bland fallback path)
+    k = 12
+    rng = np.random.default_rng(2)
+    ot = OptTransport(np.full(k, 1.0 / k), np.full(k, 1.0 / k), rng.integers(1, 20, (k, k)).astype(float))
+    ref = solve_ot(ot, "HGS", "default", settings())
+    out = solve_ot(ot, "HIP", "default", settings())
+    assert out.status == "OPTIMAL" and out.obj_val == pytest.approx(ref.obj_val, rel=1e-8)
+    X = out.x.reshape(k, k)
+    assert np.allclose(X.sum(0), 1.0 / k, atol=1e-8) and np.allclose(X.sum(1), 1.0 / k, atol=1e-8)
+
+
+def test_network_crossover_on_the_device_solver():
+    """cnet_mcf with every re-solve on the GPU: ranking, sub-problems, pricing and simplex all device."""
+    from smart_crossover.formats import MinCostFlow
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller.solving import solve_mcf
+    inst = workloads.mcf(80, 600, seed=31)
+    want = solve_mcf(MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy()), "HGS", "default",
+                     settings()).obj_val
+    with redirect_stdout(io.StringIO()):
+        out = network_crossover(inst.x, mcf=MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy()),
+                                method="cnet_mcf", solver="HIP", solver_settings=settings())
+    assert out.obj_val == pytest.approx(want, rel=1e-8)
+    E = inst.A.shape[1]
+    assert np.allclose(inst.A @ out.x[:E], inst.b, atol=1e-6) and np.all(out.x[E:] < 1e-8)
+
+
+def test_perturbation_crossover_with_split_backend():
+    """Barrier on HiGHS, every simplex-type re-solve on the device ('HGS+HIP')."""
+    from smart_crossover.lp_methods.algorithms import run_perturb_algorithm
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(150, 500, 4, seed=8, stratified=False, frac_upper=0.3)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        out = run_perturb_algorithm(lp, "HGS+HIP", 1e-10, 1e-6)
+    assert out.status == "OPTIMAL"
+    if "A primal optimal BFS is found" not in buf.getvalue():
+        check_vertex(lp, out, ref.obj_val)
