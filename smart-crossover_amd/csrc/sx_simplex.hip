@@ -765,21 +765,46 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     // ---- phases
     SpxState host;
     memset(&host, 0, sizeof(host));
+    auto enqueue_pivot = [&]() {
+        hipLaunchKernelGGL(k_spx_price, dim3(gP), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
+                           A->csc_idx, A->csc_val, opt_tol);
+        hipLaunchKernelGGL(k_spx_price_logical, dim3(gL), dim3(SX_WG), 0, s, P, gP, opt_tol);
+        hipLaunchKernelGGL(k_spx_select, dim3(1), dim3(SX_WG), 0, s, P, gP + gL);
+        hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1);
+        hipLaunchKernelGGL(k_spx_ratio, dim3(1), dim3(1024), 0, s, P);
+        hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_update_vec, dim3(gM), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_commit, dim3(1), dim3(1), 0, s, P);
+    };
+    // a batch of 32 pivots = 288 small launches with fixed arguments: captured once into a hipGraph
+    // and replayed (pivots are launch-bound for small m); direct launches are the fallback
+    const int batch = 32;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (ctx->opt_graph && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        for (int k = 0; k < batch; ++k) enqueue_pivot();
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+            exec = nullptr;
+    }
+    (void)hipGetLastError();
+    struct GraphGuard {
+        hipGraph_t &g;
+        hipGraphExec_t &e;
+        ~GraphGuard() {
+            if (e) (void)hipGraphExecDestroy(e);
+            if (g) (void)hipGraphDestroy(g);
+        }
+    } graph_guard{graph, exec};
+
     auto run_phase = [&](int64_t budget) -> int {
-        const int batch = 32;
         int64_t done_iters = 0;
         while (true) {
-            for (int k = 0; k < batch; ++k) {
-                hipLaunchKernelGGL(k_spx_price, dim3(gP), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
-                                   A->csc_idx, A->csc_val, opt_tol);
-                hipLaunchKernelGGL(k_spx_price_logical, dim3(gL), dim3(SX_WG), 0, s, P, gP, opt_tol);
-                hipLaunchKernelGGL(k_spx_select, dim3(1), dim3(SX_WG), 0, s, P, gP + gL);
-                hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1);
-                hipLaunchKernelGGL(k_spx_ratio, dim3(1), dim3(1024), 0, s, P);
-                hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P);
-                hipLaunchKernelGGL(k_spx_update_vec, dim3(gM), dim3(SX_WG), 0, s, P);
-                hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
-                hipLaunchKernelGGL(k_spx_commit, dim3(1), dim3(1), 0, s, P);
+            if (exec) {
+                SX_HIP(hipGraphLaunch(exec, s));
+            } else {
+                for (int k = 0; k < batch; ++k) enqueue_pivot();
             }
             done_iters += batch;
             SX_HIP(hipGetLastError());
