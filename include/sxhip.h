@@ -61,8 +61,9 @@ int sx_device_count(int *count);
 int sx_ctx_create(int device, void *stream, sx_ctx **out);
 int sx_ctx_destroy(sx_ctx *ctx);
 int sx_ctx_sync(sx_ctx *ctx);
-/* Tuning knobs (performance only, never results): "xcd_swizzle" 0/1 (default 1), "nt_stream" 0/1
- * (default 0), "chunk" 2048/4096 (default 4096), "window" 0/1 (default 0: per-tile LDS operand window
+/* Tuning knobs (performance only, never results): "xcd_swizzle" 0/1 (default 1), "nt_stream"
+ * (cache policy of the streamed entry loads: 0 plain [default], 1 non-temporal, 2/16/17/18 buffer loads
+ * with nt / sc1 / sc0 sc1 / nt sc1), "chunk" 2048/4096 (default 4096), "window" 0/1 (default 0: per-tile LDS operand window
  * in K1), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch).  Unknown keys return
  * SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);

@@ -81,7 +81,11 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     if (!strcmp(key, "xcd_swizzle")) {
         ctx->opt_xcd_swizzle = value ? 1 : 0;
     } else if (!strcmp(key, "nt_stream")) {
-        ctx->opt_nt_stream = value ? 1 : 0;
+        if (value != 0 && value != 1 && value != 2 && value != 16 && value != 17 && value != 18) {
+            sx_set_error("nt_stream must be 0, 1, 2, 16, 17 or 18");
+            return SX_ERR_INVALID;
+        }
+        ctx->opt_nt_stream = value;
     } else if (!strcmp(key, "chunk")) {
         SX_REQUIRE(value == 2048 || value == 4096, "chunk must be 2048 or 4096");
         ctx->opt_chunk = static_cast<int>(value);

@@ -17,7 +17,7 @@ struct StageDot {
 };
 
 // ------------------------------------------------------------------------------------- K1
-template <int CHUNK, bool NT>
+template <int CHUNK, int NT>
 __global__ __launch_bounds__(SX_WG) void k_score_columns(
     const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
 }
 
 // ------------------------------------------------------------------------------------- K2
-template <int CHUNK, bool NT>
+template <int CHUNK, int NT>
 __global__ __launch_bounds__(SX_WG) void k_score_rows(
     const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
@@ -129,7 +129,7 @@ __device__ __forceinline__ void price_block_reduce(double v, long long ix, long 
 // grid-stride over tiles: one partial per workgroup (at most PRICE_GRID of them)
 constexpr int PRICE_GRID = 2048;
 
-template <int CHUNK, bool NT>
+template <int CHUNK, int NT>
 __global__ __launch_bounds__(SX_WG) void k_price(
     const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
@@ -345,11 +345,17 @@ inline unsigned walk_grid(const sx_ctx *ctx, int64_t ntiles) {
 #define SX_DISPATCH_VARIANT(ctx, LAUNCH)                                                           \
     do {                                                                                           \
         if ((ctx)->opt_chunk == 2048) {                                                            \
-            if ((ctx)->opt_nt_stream) LAUNCH(2048, true);                                          \
-            else LAUNCH(2048, false);                                                              \
+            if ((ctx)->opt_nt_stream) LAUNCH(2048, 1);                                             \
+            else LAUNCH(2048, 0);                                                                  \
         } else {                                                                                   \
-            if ((ctx)->opt_nt_stream) LAUNCH(4096, true);                                          \
-            else LAUNCH(4096, false);                                                              \
+            switch ((ctx)->opt_nt_stream) {                                                        \
+            case 1: LAUNCH(4096, 1); break;                                                        \
+            case 2: LAUNCH(4096, 2); break;                                                        \
+            case 16: LAUNCH(4096, 16); break;                                                      \
+            case 17: LAUNCH(4096, 17); break;                                                      \
+            case 18: LAUNCH(4096, 18); break;                                                      \
+            default: LAUNCH(4096, 0); break;                                                       \
+            }                                                                                      \
         }                                                                                          \
     } while (0)
 

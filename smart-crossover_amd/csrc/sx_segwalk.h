@@ -44,21 +44,49 @@ __device__ __forceinline__ int64_t sx_tile_of_block(int64_t b, int64_t ntiles, i
 typedef int sx_v4i __attribute__((ext_vector_type(4)));
 typedef double sx_v2d __attribute__((ext_vector_type(2)));
 
-// 16-byte loads of the streamed arrays; NT marks them non-temporal so that the once-read stream
-// does not evict the gathered operand from the vector L1
-template <bool NT>
-__device__ __forceinline__ sx_v4i sx_ld_i4(const int32_t *p) {
-    if constexpr (NT)
-        return __builtin_nontemporal_load(reinterpret_cast<const sx_v4i *>(p));
-    else
-        return *reinterpret_cast<const sx_v4i *>(p);
+// 16-byte loads of the streamed entry arrays.  NT selects how they are issued:
+//   0        plain global loads;
+//   1        global loads marked non-temporal;
+//   >= 2     raw buffer loads whose cache-policy bits are NT (2 = nt, 16 = sc1, 17 = sc0 sc1,
+//            18 = nt sc1): the once-read stream is fetched at agent scope so that it does not
+//            displace the gathered operand from the 32 KB vector L1.  The descriptor is rebased
+//            to the chunk, so the 32-bit byte offsets never leave the chunk.
+struct sx_stream {
+    const int32_t *idx;
+    const double *val;
+    __amdgpu_buffer_rsrc_t ridx, rval;
+};
+
+template <int NT>
+__device__ __forceinline__ sx_stream sx_stream_at(const int32_t *idx, const double *val, int64_t base) {
+    sx_stream s;
+    s.idx = idx + base;
+    s.val = val + base;
+    if constexpr (NT >= 2) {
+        s.ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(s.idx), 0, 0x7fffffff, 0x00020000);
+        s.rval = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(s.val), 0, 0x7fffffff, 0x00020000);
+    }
+    return s;
 }
-template <bool NT>
-__device__ __forceinline__ sx_v2d sx_ld_d2(const double *p) {
-    if constexpr (NT)
-        return __builtin_nontemporal_load(reinterpret_cast<const sx_v2d *>(p));
-    else
-        return *reinterpret_cast<const sx_v2d *>(p);
+
+// entries [off, off+4) of the chunk
+template <int NT>
+__device__ __forceinline__ void sx_ld_quad(const sx_stream &s, int off, sx_v4i &i4, sx_v2d &v01, sx_v2d &v23) {
+    if constexpr (NT >= 2) {
+        i4 = __builtin_amdgcn_raw_buffer_load_b128(s.ridx, off * 4, 0, NT);
+        const sx_v4i a = __builtin_amdgcn_raw_buffer_load_b128(s.rval, off * 8, 0, NT);
+        const sx_v4i b = __builtin_amdgcn_raw_buffer_load_b128(s.rval, off * 8 + 16, 0, NT);
+        v01 = __builtin_bit_cast(sx_v2d, a);
+        v23 = __builtin_bit_cast(sx_v2d, b);
+    } else if constexpr (NT == 1) {
+        i4 = __builtin_nontemporal_load(reinterpret_cast<const sx_v4i *>(s.idx + off));
+        v01 = __builtin_nontemporal_load(reinterpret_cast<const sx_v2d *>(s.val + off));
+        v23 = __builtin_nontemporal_load(reinterpret_cast<const sx_v2d *>(s.val + off + 2));
+    } else {
+        i4 = *reinterpret_cast<const sx_v4i *>(s.idx + off);
+        v01 = *reinterpret_cast<const sx_v2d *>(s.val + off);
+        v23 = *reinterpret_cast<const sx_v2d *>(s.val + off + 2);
+    }
 }
 
 // Stage functor:  void operator()(double value, int32_t index, double (&out)[NACC]) const
@@ -71,7 +99,7 @@ struct sx_no_prologue {
 // `pre(seg, valid)` runs as soon as the lane knows its segment, before any entry is streamed: the
 // place to issue the loads an epilogue will need (c, x, l, u ...) so that their HBM latency overlaps
 // the walk instead of following it.
-template <int NACC, int CHUNK, bool NT = false, class Stage, class Pre = sx_no_prologue>
+template <int NACC, int CHUNK, int NT = 0, class Stage, class Pre = sx_no_prologue>
 __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, int64_t tile,
                                            const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx,
@@ -96,6 +124,7 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, in
 
     for (int64_t base = p_lo & ~static_cast<int64_t>(3); base < p_hi; base += CHUNK) {
         // ---- stage: CHUNK / SX_SWEEP sweeps of 1024 entries
+        const sx_stream src = sx_stream_at<NT>(idx, val, base);
 #pragma unroll
         for (int r = 0; r < CHUNK / SX_SWEEP; ++r) {
             const int64_t sweep0 = base + static_cast<int64_t>(r) * SX_SWEEP;
@@ -104,10 +133,10 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, in
                 const int64_t e = base + off;
                 // lanes past the slice re-read its first quad (cached) instead of branching;
                 // their LDS slots are never consumed
-                const int64_t ee = (e < p_hi) ? e : base;
-                const sx_v4i i4 = sx_ld_i4<NT>(idx + ee);
-                const sx_v2d v01 = sx_ld_d2<NT>(val + ee);
-                const sx_v2d v23 = sx_ld_d2<NT>(val + ee + 2);
+                const int eo = (e < p_hi) ? off : 0;
+                sx_v4i i4;
+                sx_v2d v01, v23;
+                sx_ld_quad<NT>(src, eo, i4, v01, v23);
                 double o0[NACC], o1[NACC], o2[NACC], o3[NACC];
                 stage(v01.x, i4.x, o0);
                 stage(v01.y, i4.y, o1);

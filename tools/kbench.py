@@ -42,6 +42,8 @@ def main():
     variants = list(itertools.product((0, 1), (0, 1), (4096, 2048), (0,)))   # swizzle, nt, chunk, lds-window
     if args.variants == "default":
         variants = [(1, 0, 4096, 0), (1, 0, 4096, 1)]
+    elif args.variants == "policy":   # cache policy of the streamed loads (see sx_segwalk.h)
+        variants = [(1, p, 4096, 0) for p in (0, 1, 2, 16, 17, 18)]
     res = {v: {"k1": [], "k2": []} for v in variants}
     ref = None
     for rnd in range(args.rounds):
@@ -69,7 +71,7 @@ def main():
     print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med)")
     for v in variants:
         a, b = np.array(res[v]["k1"]), np.array(res[v]["k2"])
-        print(f" {v[0]}  {v[1]}  {v[2]:4d}  {v[3]} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
+        print(f" {v[0]} {v[1]:2d}  {v[2]:4d}  {v[3]} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
               f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f}")
 
 
