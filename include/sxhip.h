@@ -63,8 +63,9 @@ int sx_ctx_destroy(sx_ctx *ctx);
 int sx_ctx_sync(sx_ctx *ctx);
 /* Tuning knobs (performance only, never results): "xcd_swizzle" 0/1 (default 1), "nt_stream"
  * (cache policy of the streamed entry loads: 0 plain [default], 1 non-temporal, 2/16/17/18 buffer loads
- * with nt / sc1 / sc0 sc1 / nt sc1), "chunk" 2048/4096 (default 4096), "window" 0/1 (default 0: per-tile LDS operand window
- * in K1), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch).  Unknown keys return
+ * with nt / sc1 / sc0 sc1 / nt sc1), "chunk" 2048/4096 (default 4096), "window" (LDS operand window of the
+ * column walk in K1/K10: -1 auto [default: decided per matrix from its index clustering on first use],
+ * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch).  Unknown keys return
  * SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */

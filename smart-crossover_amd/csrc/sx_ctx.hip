@@ -90,7 +90,7 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         SX_REQUIRE(value == 2048 || value == 4096, "chunk must be 2048 or 4096");
         ctx->opt_chunk = static_cast<int>(value);
     } else if (!strcmp(key, "window")) {
-        ctx->opt_window = value ? 1 : 0;
+        ctx->opt_window = value < 0 ? -1 : static_cast<int>(value);
     } else if (!strcmp(key, "graph")) {
         ctx->opt_graph = value ? 1 : 0;
     } else {

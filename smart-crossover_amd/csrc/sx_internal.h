@@ -63,7 +63,7 @@ struct sx_ctx {
     int opt_xcd_swizzle = 1; // XCD-contiguous block -> tile map
     int opt_nt_stream = 0;   // non-temporal loads for the streamed entry arrays
     int opt_chunk = 4096;    // staged entries per chunk (2048 or 4096)
-    int opt_window = 0;      // 1: per-tile LDS operand window in K1 (opt-in, see sx_window.hip)
+    int opt_window = -1;     // LDS operand window of the column walk: -1 auto, 0 off, 1/2/4/8 tiles per load
     int opt_graph = 1;       // replay the CG iteration batch as a hipGraph
 };
 
@@ -86,12 +86,13 @@ struct sx_matrix {
     // optional per-tile operand window of the column walk (sx_window.hip), built on first use
     mutable int32_t *csc_win_lo = nullptr;
     mutable int csc_win_tried = 0;
+    mutable int csc_win_useful = 0; // verdict of the auto rule
 };
 
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
-                    int64_t bound, int32_t **win_lo_out);
-int sx_window_score_columns(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c, const double *x,
-                            const double *l, const double *u, double gamma, double *s_d, uint8_t *code);
+                    int64_t bound, int32_t **win_lo_out, int *useful_out);
+// tiles per window load for A's column walk under ctx's "window" option (0 = plain walk)
+int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out);
 
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
                    int64_t *ntiles_out);

@@ -4,6 +4,7 @@
 // every sum below is a separately rounded binary64 operation.
 #include "sx_internal.h"
 #include "sx_segwalk.h"
+#include "sx_window.h"
 
 #include <cmath>
 
@@ -50,6 +51,54 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
         const bool low = (xj - lj) < (gamma * sd);
         const bool up = (uj - xj) < (gamma * (-sd));
         code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
+    }
+}
+
+// K1 behind an LDS operand window: one workgroup scores RUN consecutive tiles per window load
+// (sx_window.h).  Same sums, same roundings, same outputs as k_score_columns.
+template <int RUN>
+__global__ __launch_bounds__(SX_WG) void k_score_columns_lw(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
+    const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
+    int64_t m, const double *__restrict__ y, const double *__restrict__ c, const double *__restrict__ x,
+    const double *__restrict__ l, const double *__restrict__ u, double gamma, double *__restrict__ s_d,
+    uint8_t *__restrict__ code) {
+    __shared__ sx_walk_lds<1, SXL_CHUNK> lds;
+    __shared__ double win[SXL_CAP];
+    const int64_t nruns = (ntiles + RUN - 1) / RUN;
+    const int64_t run = sx_tile_of_block(blockIdx.x, nruns, swizzle);
+    if (run >= nruns) return;
+    const int64_t t0 = run * RUN;
+    const int64_t t1 = (t0 + RUN < ntiles) ? t0 + RUN : ntiles;
+    const int64_t wlo = win_lo[(t0 + t1 - 1) >> 1]; // window of the run's middle tile
+    sx_window_fill(win, y, wlo, m);
+    __syncthreads();
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        double acc[1];
+        int64_t j;
+        bool valid;
+        double cj = 0.0, xj = 0.0, lj = 0.0, uj = 0.0;
+        auto pre = [&](int64_t seg, bool ok) {
+            if (ok) {
+                cj = c[seg];
+                if (code) {
+                    xj = x[seg];
+                    lj = l[seg];
+                    uj = u[seg];
+                }
+            }
+        };
+        sx_segwalk<1, SXL_CHUNK, 0>(tiles, tile, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, j, valid,
+                                    acc, pre);
+        if (valid) {
+            const double sd = cj - acc[0];
+            if (s_d) s_d[j] = sd;
+            if (code) {
+                const bool low = (xj - lj) < (gamma * sd);
+                const bool up = (uj - xj) < (gamma * (-sd));
+                code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
+            }
+        }
     }
 }
 
@@ -160,6 +209,50 @@ __global__ __launch_bounds__(SX_WG) void k_price(
             if (rc_out) rc_out[j] = rc;
             bad += (rc >= -tol) ? 0 : 1;
             if (rc == rc) price_combine(v, ix, rc, j); // NaN never becomes the minimum
+        }
+    }
+    price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
+}
+
+// K10 behind the LDS operand window: grid-stride over runs of RUN tiles, one window load per run
+template <int RUN>
+__global__ __launch_bounds__(SX_WG) void k_price_lw(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
+    const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
+    int64_t m, const double *__restrict__ y, const double *__restrict__ c, const int8_t *__restrict__ vbasis,
+    double tol, double *__restrict__ rc_out, PricePartial *__restrict__ partial) {
+    __shared__ sx_walk_lds<1, SXL_CHUNK> lds;
+    __shared__ double win[SXL_CAP];
+    double v = 0.0;
+    long long ix = -1, bad = 0;
+    const int64_t nruns = (ntiles + RUN - 1) / RUN;
+    int64_t r = blockIdx.x, r_end = nruns, r_step = gridDim.x;
+    if (swizzle) { // gridDim.x is a multiple of 8: XCD k walks the contiguous runs [k*per, (k+1)*per)
+        const int64_t per = (nruns + 7) >> 3;
+        r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        r_end = ((blockIdx.x & 7) + 1) * per;
+        if (r_end > nruns) r_end = nruns;
+        r_step = gridDim.x >> 3;
+    }
+    for (; r < r_end; r += r_step) {
+        const int64_t t0 = r * RUN;
+        const int64_t t1 = (t0 + RUN < ntiles) ? t0 + RUN : ntiles;
+        const int64_t wlo = win_lo[(t0 + t1 - 1) >> 1];
+        __syncthreads(); // the previous run's gathers are done with the window
+        sx_window_fill(win, y, wlo, m);
+        __syncthreads();
+        for (int64_t t = t0; t < t1; ++t) {
+            double acc[1];
+            int64_t j;
+            bool valid;
+            sx_segwalk<1, SXL_CHUNK, 0>(tiles, t, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, j, valid, acc);
+            if (valid) {
+                double rc = c[j] - acc[0];
+                if (vbasis && vbasis[j] == -2) rc = -rc;
+                if (rc_out) rc_out[j] = rc;
+                bad += (rc >= -tol) ? 0 : 1;
+                if (rc == rc) price_combine(v, ix, rc, j);
+            }
         }
     }
     price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
@@ -372,12 +465,25 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     SX_REQUIRE(y && c, "y or c is NULL");
     SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
     if (A->n == 0) return SX_OK;
-    if (ctx->opt_window) { // opt-in LDS operand window; its per-tile table is built on first use
-        if (!A->csc_win_tried) {
-            A->csc_win_tried = 1;
-            SX_TRY(sx_window_setup(ctx, A->csc_tiles, A->n_csc_tiles, A->csc_ptr, A->csc_idx, A->m, &A->csc_win_lo));
-        }
-        if (A->csc_win_lo) return sx_window_score_columns(ctx, A, y, c, x, l, u, gamma, s_d, code);
+    int run = 0; // LDS operand window (sx_window.h): table built on first use, auto rule decides
+    SX_TRY(sx_window_run_csc(ctx, A, &run));
+    if (run) {
+        const int swz = ctx->opt_xcd_swizzle;
+#define SX_LAUNCH_K1W(R)                                                                           \
+    do {                                                                                           \
+        const int64_t nruns = (A->n_csc_tiles + (R)-1) / (R);                                      \
+        hipLaunchKernelGGL((k_score_columns_lw<R>), dim3(walk_grid(ctx, nruns)), dim3(SX_WG), 0,   \
+                           ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo,          \
+                           A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d,    \
+                           code);                                                                  \
+    } while (0)
+        if (run == 8) SX_LAUNCH_K1W(8);
+        else if (run == 4) SX_LAUNCH_K1W(4);
+        else if (run == 2) SX_LAUNCH_K1W(2);
+        else SX_LAUNCH_K1W(1);
+#undef SX_LAUNCH_K1W
+        SX_HIP(hipGetLastError());
+        return SX_OK;
     }
     const unsigned grid = walk_grid(ctx, A->n_csc_tiles);
 #define SX_LAUNCH_K1(CH, NTV)                                                                      \
@@ -494,6 +600,23 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     }
     SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(PricePartial)));
     PricePartial *partial = static_cast<PricePartial *>(ctx->ws);
+    int run = 0;
+    SX_TRY(sx_window_run_csc(ctx, A, &run));
+    if (run) {
+#define SX_LAUNCH_K10W(R)                                                                          \
+    hipLaunchKernelGGL((k_price_lw<R>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,       \
+                       A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val,     \
+                       A->m, y, c, vbasis, tol, rc, partial)
+        if (run == 8) SX_LAUNCH_K10W(8);
+        else if (run == 4) SX_LAUNCH_K10W(4);
+        else if (run == 2) SX_LAUNCH_K10W(2);
+        else SX_LAUNCH_K10W(1);
+#undef SX_LAUNCH_K10W
+        hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial,
+                           static_cast<int64_t>(nb), result_dev);
+        SX_HIP(hipGetLastError());
+        return SX_OK;
+    }
 #define SX_LAUNCH_K10(CH, NTV)                                                                     \
     hipLaunchKernelGGL((k_price<CH, NTV>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,    \
                        A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx, A->csc_val, y, c, vbasis, tol, \

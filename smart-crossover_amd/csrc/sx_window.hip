@@ -1,32 +1,30 @@
-// Optional LDS operand window for the column walk (K1), off by default ("window" option = 1 enables).
+// Window table of the column walk (see sx_window.h): per tile, the start of the SXL_CAP-long index
+// window that covers most of the tile's entries, plus the statistics the "auto" mode decides on.
+// Built once per matrix, on the first K1 / K10 call that may use it.
 //
-// With the plain walk (sx_segwalk.h) HBM traffic is already minimal, but every y[row] gather is its own
-// vector-L1 lookup and ~45 % of them miss the 32 KiB L1 at the default workload (profiles/r01/pmc_*.txt):
-// K1 runs at 0.6-0.7 of the HBM peak when the gathers hit (narrow staircase) and at 0.45 when they do
-// not.  This variant serves most gathers from LDS: each 256-lane workgroup loads, with coalesced loads
-// whose latency overlaps the entry stream, the 32 KiB window of the operand (4096 doubles) that covers
-// most row indices of its tile; indices outside the window fall back to global memory, so results are
-// bit-identical to the plain walk.  48 KiB of LDS -> 3 workgroups per CU.
-//
-// Measured (profiles/r01/kbench_window_variants.txt): +10 % at the default staircase window (W = 4096
-// rows), -19 % when the gathers already hit L1 (W = 64), neutral without locality.  A second design --
-// persistent 1024-lane workgroups sharing a sliding 64 KiB ring with register prefetch -- was built and
-// measured slower everywhere (16 waves in lockstep lose the overlap that five independent workgroups
-// per CU provide) and was removed.  Hence: opt-in, not default.
+// Measured on MI355X, c5 shard (profiles/r01/kbench_window_run.txt), K1 in ms, plain -> windowed run of 4:
+//   staircase window   64 rows : 0.305 -> 0.329   (gathers already hit L1: window load is pure overhead)
+//   staircase window 4096 rows : 0.424 -> 0.344
+//   staircase window  32 Ki rows: 0.477 -> 0.463
+// Hence auto mode: windowed only when at least half of the sampled indices fall inside the window and
+// the window is actually wide (median extent >= 1024 rows).  Two further designs were built, measured
+// slower and removed: persistent 1024-lane workgroups sharing a sliding 64 KiB ring, and a register
+// prefetch of tile t+1's entries while tile t is summed (no gain: the walk is not latency-bound).
 #include "sx_internal.h"
-#include "sx_segwalk.h"
+#include "sx_window.h"
+
+#include <algorithm>
 
 namespace {
 
-constexpr int SXL_CAP = 4096;      // window length (doubles)
-constexpr int SXL_THREADS = 1024;  // setup kernel: sample size for the densest-window search
+constexpr int SXL_THREADS = 1024; // sample size for the densest-window search
 
-// per tile: start of the SXL_CAP-long index window that covers most of the tile's entries,
-// found on an evenly spaced sample of up to 1024 entries (sorted in LDS, then one binary search each)
+// sample up to 1024 evenly spaced entries of the tile, sort them in LDS, then one binary search per
+// sample value counts how many samples fall in [value, value + CAP)
 __global__ __launch_bounds__(SXL_THREADS) void k_win_lo(const int64_t *__restrict__ tiles, int64_t ntiles,
                                                         const int64_t *__restrict__ ptr,
                                                         const int32_t *__restrict__ idx, int64_t bound,
-                                                        int32_t *__restrict__ win_lo) {
+                                                        int32_t *__restrict__ win_lo, int32_t *__restrict__ stat) {
     __shared__ int32_t s[SXL_THREADS];
     __shared__ int best_cnt[SXL_THREADS / 64];
     __shared__ int best_pos[SXL_THREADS / 64];
@@ -53,7 +51,7 @@ __global__ __launch_bounds__(SXL_THREADS) void k_win_lo(const int64_t *__restric
             __syncthreads();
         }
     int count = 0;
-    if (s[tid] != INT32_MAX) { // sample values in [s[tid], s[tid] + CAP)
+    if (s[tid] != INT32_MAX) {
         const int64_t lim = static_cast<int64_t>(s[tid]) + SXL_CAP;
         int lo = tid, hi = SXL_THREADS;
         while (lo < hi) {
@@ -84,94 +82,70 @@ __global__ __launch_bounds__(SXL_THREADS) void k_win_lo(const int64_t *__restric
                 pos = best_pos[w];
             }
         int64_t lo = (count > 0) ? s[pos] : 0;
+        const int32_t extent = (count > 0) ? s[pos + count - 1] - s[pos] + 1 : 0;
         if (lo > bound - SXL_CAP) lo = bound - SXL_CAP;
         if (lo < 0) lo = 0;
         win_lo[t] = static_cast<int32_t>(lo);
-    }
-}
-
-struct StageWin {
-    const double *__restrict__ vec;
-    const double *win;
-    int64_t wlo;
-    __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[1]) const {
-        const uint64_t d = static_cast<uint64_t>(static_cast<int64_t>(i) - wlo);
-        const double yv = (d < static_cast<uint64_t>(SXL_CAP)) ? win[d] : vec[i];
-        o[0] = v * yv;
-    }
-};
-
-__global__ __launch_bounds__(SX_WG) void k_score_columns_lw(
-    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
-    const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
-    int64_t m, const double *__restrict__ y, const double *__restrict__ c, const double *__restrict__ x,
-    const double *__restrict__ l, const double *__restrict__ u, double gamma, double *__restrict__ s_d,
-    uint8_t *__restrict__ code) {
-    __shared__ sx_walk_lds<1, 2048> lds;
-    __shared__ double win[SXL_CAP];
-    const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
-    if (tile >= ntiles) return;
-    const int64_t wlo = win_lo[tile];
-#pragma unroll
-    for (int r = 0; r < SXL_CAP / SX_WG; ++r) { // 16 independent coalesced 8-byte loads per lane
-        const int k = r * SX_WG + threadIdx.x;
-        int64_t row = wlo + k;
-        if (row > m - 1) row = m - 1;
-        win[k] = y[row];
-    }
-    __syncthreads();
-    double acc[1];
-    int64_t j;
-    bool valid;
-    double cj = 0.0, xj = 0.0, lj = 0.0, uj = 0.0;
-    auto pre = [&](int64_t seg, bool ok) {
-        if (ok) {
-            cj = c[seg];
-            if (code) {
-                xj = x[seg];
-                lj = l[seg];
-                uj = u[seg];
-            }
-        }
-    };
-    sx_segwalk<1, 2048, false>(tiles, tile, colptr, rowidx, val, StageWin{y, win, wlo}, lds, j, valid, acc, pre);
-    if (!valid) return;
-    const double sd = cj - acc[0];
-    if (s_d) s_d[j] = sd;
-    if (code) {
-        const bool low = (xj - lj) < (gamma * sd);
-        const bool up = (uj - xj) < (gamma * (-sd));
-        code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
+        stat[3 * t + 0] = count;                                                   // samples covered
+        stat[3 * t + 1] = static_cast<int32_t>(cnt < SXL_THREADS ? cnt : SXL_THREADS); // samples taken
+        stat[3 * t + 2] = extent;                                                  // rows they span
     }
 }
 
 } // namespace
 
-// window table of one pointer array; *win_lo_out stays NULL when the operand is shorter than a window
+// *win_lo_out stays NULL when the operand is shorter than a window; *useful_out = 1 when the auto rule
+// (file header) says the windowed walk should pay off on this matrix
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
-                    int64_t bound, int32_t **win_lo_out) {
+                    int64_t bound, int32_t **win_lo_out, int *useful_out) {
     *win_lo_out = nullptr;
+    *useful_out = 0;
     if (ntiles == 0 || bound < SXL_CAP) return SX_OK;
-    int32_t *wl = nullptr;
+    int32_t *wl = nullptr, *stat = nullptr;
     SX_HIP(hipMalloc(reinterpret_cast<void **>(&wl), sizeof(int32_t) * ntiles));
+    if (hipMalloc(reinterpret_cast<void **>(&stat), sizeof(int32_t) * 3 * ntiles) != hipSuccess) {
+        (void)hipFree(wl);
+        sx_set_error("out of device memory for the window statistics");
+        return SX_ERR_NOMEM;
+    }
     hipLaunchKernelGGL(k_win_lo, dim3(static_cast<unsigned>(ntiles)), dim3(SXL_THREADS), 0, ctx->stream, tiles, ntiles,
-                       ptr, idx, bound, wl);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                       ptr, idx, bound, wl, stat);
+    std::vector<int32_t> h(static_cast<size_t>(3 * ntiles));
+    const bool ok = hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(h.data(), stat, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream) ==
+                        hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess;
+    (void)hipFree(stat);
+    if (!ok) {
         (void)hipFree(wl);
         sx_set_error("window table kernel failed");
         return SX_ERR_HIP;
     }
+    int64_t covered = 0, taken = 0;
+    std::vector<int32_t> extent(static_cast<size_t>(ntiles));
+    for (int64_t t = 0; t < ntiles; ++t) {
+        covered += h[3 * t];
+        taken += h[3 * t + 1];
+        extent[t] = h[3 * t + 2];
+    }
+    std::nth_element(extent.begin(), extent.begin() + ntiles / 2, extent.end());
+    *useful_out = (taken > 0 && 2 * covered >= taken && extent[ntiles / 2] >= 1024) ? 1 : 0;
     *win_lo_out = wl;
     return SX_OK;
 }
 
-int sx_window_score_columns(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c, const double *x,
-                            const double *l, const double *u, double gamma, double *s_d, uint8_t *code) {
-    const int swz = ctx->opt_xcd_swizzle;
-    const unsigned grid = swz ? static_cast<unsigned>(((A->n_csc_tiles + 7) >> 3) << 3)
-                              : static_cast<unsigned>(A->n_csc_tiles);
-    hipLaunchKernelGGL(k_score_columns_lw, dim3(grid), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz,
-                       A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d, code);
-    SX_HIP(hipGetLastError());
+// tiles per window load the column walk of A should use under the context's "window" option
+// (-1 auto, 0 off, 1/2/4/8 forced); 0 = plain walk.  Builds the table on first use.
+int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out) {
+    *run_out = 0;
+    if (ctx->opt_window == 0 || !A->csc_ptr) return SX_OK;
+    if (!A->csc_win_tried) {
+        A->csc_win_tried = 1;
+        SX_TRY(sx_window_setup(ctx, A->csc_tiles, A->n_csc_tiles, A->csc_ptr, A->csc_idx, A->m, &A->csc_win_lo,
+                               &A->csc_win_useful));
+    }
+    if (!A->csc_win_lo) return SX_OK;
+    if (ctx->opt_window < 0) *run_out = A->csc_win_useful ? 4 : 0;
+    else *run_out = ctx->opt_window >= 8 ? 8 : ctx->opt_window >= 4 ? 4 : ctx->opt_window >= 2 ? 2 : 1;
     return SX_OK;
 }

@@ -38,13 +38,19 @@ def main():
     s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
     k1_bytes = 12 * sh.col_block.nnz + 49 * nb + 8 * m
     k2_bytes = 12 * sh.row_block.nnz + 8 * nb + 33 * m
+    k10_bytes = k1_bytes - 24 * nb   # reads idx/val/colptr/c/vbasis/y, writes rc
+    vb = ctx.to_device(np.where(np.arange(nb) % 7 == 0, -2, -1).astype(np.int8))
+    rc = ctx.empty(nb, np.float64)
+    pres = None
 
     variants = list(itertools.product((0, 1), (0, 1), (4096, 2048), (0,)))   # swizzle, nt, chunk, lds-window
     if args.variants == "default":
         variants = [(1, 0, 4096, 0), (1, 0, 4096, 1)]
+    elif args.variants == "window":   # LDS operand window, tiles per workgroup
+        variants = [(1, 0, 4096, w) for w in (0, 1, 4, -1)]
     elif args.variants == "policy":   # cache policy of the streamed loads (see sx_segwalk.h)
         variants = [(1, p, 4096, 0) for p in (0, 1, 2, 16, 17, 18)]
-    res = {v: {"k1": [], "k2": []} for v in variants}
+    res = {v: {"k1": [], "k2": [], "k10": []} for v in variants}
     ref = None
     for rnd in range(args.rounds):
         for v in variants:
@@ -60,19 +66,27 @@ def main():
             for _ in range(args.reps):
                 ctx.score_rows(dR, d["x"], d["b"], d["y"], 1e-3, s_p, flag)
             ctx.marker(2)
+            pres = ctx.price(dC, d["y"], d["c"], vb, 1e-6, rc, pres)
+            ctx.marker(3)
+            for _ in range(args.reps):
+                ctx.price(dC, d["y"], d["c"], vb, 1e-6, rc, pres)
+            ctx.marker(4)
+            res[v]["k10"].append(ctx.marker_elapsed(3, 4) / args.reps)
             res[v]["k1"].append(ctx.marker_elapsed(0, 1) / args.reps)
             res[v]["k2"].append(ctx.marker_elapsed(1, 2) / args.reps)
             if rnd == 0:   # knobs must never change results
-                got = (s_d.download().tobytes(), code.download().tobytes(), s_p.download().tobytes(), flag.download().tobytes())
+                got = (s_d.download().tobytes(), code.download().tobytes(), s_p.download().tobytes(), flag.download().tobytes(),
+                       rc.download().tobytes(), pres.download().tobytes())
                 if ref is None:
                     ref = got
                 assert got == ref, f"variant {v} changed the results"
     print(f"workload {args.workload}/{structure} window={args.window}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
-    print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med)")
+    print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med) | K10 med ms   min ms   GB/s(med)")
     for v in variants:
-        a, b = np.array(res[v]["k1"]), np.array(res[v]["k2"])
-        print(f" {v[0]} {v[1]:2d}  {v[2]:4d}  {v[3]} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
-              f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f}")
+        a, b, p10 = np.array(res[v]["k1"]), np.array(res[v]["k2"]), np.array(res[v]["k10"])
+        print(f" {v[0]} {v[1]:2d}  {v[2]:4d} {v[3]:3d} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
+              f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f} |"
+              f"  {np.median(p10):8.4f} {p10.min():8.4f} {k10_bytes/np.median(p10)/1e6:9.0f}")
 
 
 if __name__ == "__main__":
