@@ -261,3 +261,37 @@ def test_matrix_roundtrip_and_library_csc(ctx):
     ctx.score_columns(dA, ctx.to_device(y), ctx.to_device(c), None, None, None, 0.0, s_d, None)
     assert bits_equal(s_d.download(), L.dual_slack(A, c, y))
     dA.free()
+
+
+@pytest.mark.parametrize("structure,window", [("staircase", 4096), ("staircase", 300), ("uniform", 4096)])
+def test_window_option_never_changes_results(ctx, structure, window):
+    """K1 and K10 behind the LDS operand window (off / 1 / 2 / 4 / 8 tiles per load / auto) against the
+    oracle: the window only changes where an operand is read from, never a bit of the result.  The
+    staircase shard has 1/4 of its entries outside any 4096-row window (fallback path); the uniform
+    one has nearly all of them outside."""
+    sh = workloads.lp_shard(0, 1, m=40_000, n_block=300_000, k=8, structure=structure, window=window)
+    A = sh.col_block
+    dC = ctx.column_shard(A)
+    n = A.shape[1]
+    d = {k: ctx.to_device(getattr(sh, k)) for k in ("y", "x", "c", "l", "u")}
+    want_sd = sh.c - A.T @ sh.y                 # CSR matvec of the transposed view: stored order per column
+    want_code = L.column_codes(sh.x, sh.l, sh.u, want_sd, L.GAMMA0)
+    rng = np.random.default_rng(5)
+    vb = rng.integers(-2, 1, n).astype(np.int8)
+    want_rc = N.mcf_reduced_cost(A, sh.c, sh.y, vb.astype(int))
+    dvb = ctx.to_device(vb)
+    try:
+        for opt in (0, 1, 2, 4, 8, -1):
+            ctx.set_option("window", opt)
+            s_d, code, rc = ctx.empty(n, np.float64), ctx.empty(n, np.uint8), ctx.empty(n, np.float64)
+            ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], L.GAMMA0, s_d, code)
+            res = ctx.price(dC, d["y"], d["c"], dvb, 1e-6, rc)
+            assert bits_equal(s_d.download(), want_sd), opt
+            assert np.array_equal(code.download(), want_code), opt
+            assert bits_equal(rc.download(), want_rc), opt
+            mn, am, bad = ctx.read_price(res)
+            assert mn == want_rc.min() and am == int(np.flatnonzero(want_rc == want_rc.min())[0]), opt
+            assert bad == int(np.count_nonzero(~(want_rc >= -1e-6))), opt
+    finally:
+        ctx.set_option("window", -1)
+        dC.free()
