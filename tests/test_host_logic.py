@@ -301,3 +301,60 @@ def test_distributed_partition_and_price_reduction():
     assert tie == (-2.0, 11, 0)
     none = D.reduce_price_records([(0.0, -1, 0)], [0])
     assert none[1] == -1 and np.isnan(none[0])
+
+
+MPS_TINY = """NAME          TINY
+ROWS
+ N  COST
+ L  LIM1
+ G  LIM2
+ E  MYEQN
+ L  RNG
+COLUMNS
+    X         COST         1.0   LIM1         1.0
+    X         LIM2         1.0   RNG          1.0
+    Y         COST         2.0   LIM1         1.0
+    Y         MYEQN       -1.0   RNG          1.0
+    Z         COST        -1.0   MYEQN        1.0
+RHS
+    RHS       LIM1         4.0   LIM2         1.0
+    RHS       MYEQN        7.0   RNG          3.0
+RANGES
+    RNG       RNG          2.5
+BOUNDS
+ UP BND       X            4.0
+ LO BND       Y           -1.0
+ UP BND       Y            1.0
+ENDATA
+"""
+
+
+def test_mps_file_to_general_lp_row_form(tmp_path):
+    """read_model_from_file + return_genlp (reference: gurobi.py:25-29 + caller.py:124-126): only '=' and
+    '<' rows come back -- a 'G' row negated, a ranged row split in two -- and the LP solves to the same
+    optimum through the file, through the returned GeneralLP and through the device-free HiGHS path."""
+    from smart_crossover.solver_caller.solving import generate_solver_caller, solve_lp
+    from smart_crossover.solver_caller.caller import SolverSettings
+    path = tmp_path / "tiny.mps"
+    path.write_text(MPS_TINY)
+    quiet = SolverSettings(log_console=0)
+    caller = generate_solver_caller("HGS", quiet)
+    caller.read_model_from_file(str(path))
+    lp = caller.return_genlp()
+    assert set(lp.sense) <= {"=", "<"}
+    assert lp.A.shape == (5, 3) and list(lp.sense).count("=") == 1       # E + L + G + 2 x ranged
+    dense = {tuple(np.round(r, 12)) + (round(float(b), 12), s) for r, b, s in zip(lp.A.toarray(), lp.b, lp.sense)}
+    assert (0.0, -1.0, 1.0, 7.0, "=") in dense                           # MYEQN
+    assert (1.0, 1.0, 0.0, 4.0, "<") in dense                            # LIM1
+    assert (-1.0, 0.0, 0.0, -1.0, "<") in dense                          # LIM2:  x >= 1  ->  -x <= -1
+    assert (1.0, 1.0, 0.0, 3.0, "<") in dense and (-1.0, -1.0, 0.0, -0.5, "<") in dense   # 0.5 <= x + y <= 3
+    assert np.array_equal(lp.l, [0.0, -1.0, 0.0]) and np.array_equal(lp.u, [4.0, 1.0, np.inf])
+    caller.run_default()
+    out_file = caller.return_output()
+    out_lp = solve_lp(lp, solver="HGS", method="default", settings=quiet)
+    assert out_file.status == out_lp.status == "OPTIMAL"
+    # min x + 2y - z with z = 7 + y, i.e. min x + y - 7 over x + y >= 0.5, x >= 1, y >= -1: optimum -6.5
+    # on the face x + y = 0.5 (not a unique vertex)
+    assert abs(out_file.obj_val - (-6.5)) < 1e-9 and abs(out_lp.obj_val - (-6.5)) < 1e-9
+    x, y, z = out_lp.x
+    assert abs(x + y - 0.5) < 1e-9 and abs(z - (7.0 + y)) < 1e-9 and x >= 1 - 1e-9 and y >= -1 - 1e-9
