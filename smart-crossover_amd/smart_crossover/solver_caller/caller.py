@@ -42,6 +42,21 @@ class SolverCaller:
         self.settings = solver_settings if solver_settings is not None else SolverSettings()
 
     # -- loading -------------------------------------------------------------------------------
+    def _log_summary(self, seconds: float, iters: int, bar_iters: Optional[int] = None) -> None:
+        """Gurobi-style summary lines, so that the reference's log analysis keeps working on logs of any
+        backend (visualization.py:31-34,345-346 parse exactly these two sentences)."""
+        lines = []
+        if bar_iters is not None:
+            lines.append(f"Barrier solved model in {int(bar_iters)} iterations and {seconds:.2f} seconds")
+        if iters is not None:
+            lines.append(f"Solved in {int(iters)} iterations and {seconds:.2f} seconds")
+        if self.settings.log_file:
+            with open(self.settings.log_file, "a") as fh:
+                fh.write("".join(line + "\n" for line in lines))
+        if self.settings.log_console:
+            for line in lines:
+                print(line)
+
     def read_model_from_file(self, path: str) -> None:
         raise NotImplementedError
 

@@ -208,6 +208,8 @@ class HgsCaller(SolverCaller):
         self._crossover_off = self._used_ipm and crossover == "off"
         self._x_bar = None
         self._ran = True
+        self._log_summary(self._runtime, None if self._crossover_off else self._iters,
+                          self._bar_iters if self._used_ipm else None)
 
     def run_barrier_no_crossover(self) -> None:
         self._run("ipm", "off")

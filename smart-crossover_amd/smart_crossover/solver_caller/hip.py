@@ -100,6 +100,7 @@ class HipCaller(SolverCaller):
         self._vb, self._cb = d_vb.download().astype(int), d_cb.download().astype(int)
         if own:
             dA.free()
+        self._log_summary(self._runtime, int(self._res.iters))
 
     def run_default(self) -> None:
         self._solve()

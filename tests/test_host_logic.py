@@ -358,3 +358,24 @@ def test_mps_file_to_general_lp_row_form(tmp_path):
     assert abs(out_file.obj_val - (-6.5)) < 1e-9 and abs(out_lp.obj_val - (-6.5)) < 1e-9
     x, y, z = out_lp.x
     assert abs(x + y - 0.5) < 1e-9 and abs(z - (7.0 + y)) < 1e-9 and x >= 1 - 1e-9 and y >= -1 - 1e-9
+
+
+def test_gurobi_style_summary_lines_in_log(tmp_path):
+    """The two sentences the reference's log analysis parses (visualization.py:31-34,345-346) are appended
+    to SolverSettings.log_file by every backend run."""
+    import re
+    from smart_crossover.solver_caller.solving import solve_lp
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.formats import GeneralLP
+    inst = workloads.config1()
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    log = tmp_path / "run.log"
+    st = SolverSettings(log_console=0, log_file=str(log))
+    out_b = solve_lp(lp, solver="HGS", method="barrier", settings=st)
+    out_s = solve_lp(lp, solver="HGS", method="primal_simplex", settings=st)
+    assert out_b.status == out_s.status == "OPTIMAL"
+    text = log.read_text()
+    bar = re.findall(r"Barrier solved model in (\d+) iterations and (\d+\.\d+) seconds", text)
+    spx = re.findall(r"Solved in (\d+) iterations and (\d+\.\d+) seconds", text)
+    assert len(bar) == 1 and int(bar[0][0]) == out_b.bar_iter_count
+    assert len(spx) == 2 and int(spx[1][0]) == out_s.iter_count
