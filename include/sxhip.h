@@ -217,6 +217,14 @@ int sx_flow_indicator_mcf_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, 
 int sx_flow_indicator_ot_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *X, const double *s,
                              const double *d, double *ind);
 
+/* ------------------------------------------------------------------ K13: TNET spanning tree
+ * replaces max_weight_spanning_tree (network_methods/tree_BI.py:32-59: scipy minimum_spanning_tree of
+ * the negated weights on the bipartite supplier x demander graph).  w: S*D flow weights, row-major;
+ * arcs with w <= 0 (or NaN) are not edges.  in_tree: S*D flags, 1 on the arcs of the maximum-weight
+ * spanning forest (S + D - 1 arcs when the positive-weight graph is connected).  Equal weights are
+ * ordered by ascending arc index (the reference's order among ties is unspecified). */
+int sx_spanning_tree_ot_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *w, uint8_t *in_tree);
+
 /* ------------------------------------------------------------------ K9: ranking
  * replaces np.argsort(indicators)[::-1] (network_methods/net_manager.py:184,379).  The reference's
  * default sort is unstable, so ties are defined here: descending key; equal keys by descending

@@ -197,6 +197,12 @@ class Context:
     def flow_indicator_ot(self, S, D, X, s, d, ind) -> None:
         _l.check(self._lib.sx_flow_indicator_ot_dev(self.handle, int(S), int(D), _ptr(X), _ptr(s), _ptr(d), _ptr(ind)))
 
+    def spanning_tree_ot(self, S, D, w: "DeviceArray") -> np.ndarray:
+        """K13: arc indices (ascending) of the maximum-weight spanning forest of the S x D bipartite graph."""
+        flags = self.empty(max(int(S) * int(D), 1), np.uint8)
+        _l.check(self._lib.sx_spanning_tree_ot_dev(self.handle, int(S), int(D), _ptr(w), flags.ptr))
+        return self.where(flags, 0xFF) if int(S) * int(D) else np.zeros(0, dtype=np.int64)
+
     def argsort_desc(self, key: "DeviceArray", out: Optional["DeviceArray"] = None) -> "DeviceArray":
         if out is None:
             out = self.empty(key.size, np.int64)

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "sx_gather_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_flow_indicator_mcf_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_flow_indicator_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sx_spanning_tree_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "sx_argsort_desc_dev": (_int, [_vp, _i64, _vp, _vp]),
     "sx_price_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _dbl, _vp, _vp]),
     "sx_projector_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, C.POINTER(CgResult)]),

@@ -1,12 +1,13 @@
 """TNET tree basis identification -- API of the reference's ``network_methods/tree_BI.py``
 (tree_basis_identify :12, max_weight_spanning_tree :32, push_tree_to_bfs :62).
 
-Three small, inherently sequential steps on an (S + D)-node bipartite graph; they run on the host,
-like in the reference (not bandwidth relevant -- 1.5 k tree edges and a few
-hundred pushes at the 784 x 784 configuration):
+K13 scans all S*D arcs and runs on the device; K14 and K15 touch only the S + D - 1 tree arcs (1.5 k at
+the 784 x 784 configuration, a few hundred pushes) and stay on the host, like in the reference:
 
-  K13  maximum-weight spanning tree of the arcs with a non-zero indicator (scipy csgraph, the same
-       routine the reference calls; arcs with indicator 0 are not edges, exactly as there)
+  K13  maximum-weight spanning tree of the arcs with a non-zero indicator: Boruvka on the device
+       (csrc/sx_tree.hip; the reference calls scipy's minimum_spanning_tree on the negated weights,
+       125 ms at 784 x 784 -- mostly its argsort of 614,656 weights; arcs with indicator 0 are not
+       edges, exactly as there)
   K14  the tree system B x_B = b, solved by leaf elimination in O(S + D) instead of a sparse LU
   K15  the "push" loop that removes negative tree flows along 4-cycles
 """
@@ -16,9 +17,6 @@ from collections import deque
 from typing import Tuple
 
 import numpy as np
-from scipy import sparse as sp
-from scipy.sparse import csgraph
-
 from smart_crossover.formats import OptTransport
 from smart_crossover.network_methods.net_manager import OTManager
 from smart_crossover.output import Basis
@@ -36,12 +34,13 @@ def tree_basis_identify(ot_manager: OTManager, flow_weights: np.ndarray) -> Tupl
 def max_weight_spanning_tree(ot: OptTransport, flow_weights: np.ndarray) -> np.ndarray:
     """Linear arc indices (i*D + j, ascending) of a maximum-weight spanning tree of the bipartite
     graph suppliers x demanders weighted by ``flow_weights``."""
+    from smart_crossover.hip.device import default_context
     S, D = ot.M.shape
-    w = np.asarray(flow_weights, dtype=float).reshape(S, D)
-    # upper-right block of the (S+D) x (S+D) adjacency: supplier i -- node S + j, weight -w_ij
-    graph = sp.bmat([[None, sp.csr_matrix(-w)], [sp.csr_matrix((D, S)), None]], format="csr")
-    tree = csgraph.minimum_spanning_tree(graph).tocoo()
-    return np.sort(tree.row.astype(np.int64) * D + (tree.col.astype(np.int64) - S))
+    ctx = default_context()
+    w = ctx.to_device(np.ascontiguousarray(flow_weights, dtype=np.float64).reshape(-1))
+    tree = ctx.spanning_tree_ot(S, D, w)      # K13 on the device: Boruvka, sx_spanning_tree_ot_dev
+    w.free()
+    return tree
 
 
 def _solve_tree_flows(S: int, D: int, tree: np.ndarray, s: np.ndarray, d: np.ndarray) -> np.ndarray:

@@ -153,3 +153,14 @@ def test_network_crossover_rejects_unknown_method():
     from smart_crossover.network_methods.algorithms import network_crossover
     with pytest.raises(ValueError):
         quiet(network_crossover, np.zeros(4), method="simplex", solver="HGS")
+
+
+def test_tree_basis_identify_rejects_disconnected_support():
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.net_manager import OTManager
+    from smart_crossover.network_methods import tree_BI
+    ot = OptTransport(np.array([0.5, 0.5]), np.array([0.5, 0.5]), np.ones((2, 2)))
+    mgr = OTManager(ot)
+    mgr.get_mcf()
+    with pytest.raises(ValueError):
+        tree_BI.tree_basis_identify(mgr, np.array([1.0, 0.0, 0.0, 1.0]))

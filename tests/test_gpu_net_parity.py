@@ -123,3 +123,54 @@ def test_argsort_desc_special_values(ctx):
     # numpy puts NaN last in ascending order (hence first here) and treats -0.0 == +0.0 as a tie
     assert np.array_equal(q, N.rank_desc(key))
     assert set(q[:2].tolist()) == {2, 9}
+
+
+# ----------------------------------------------------------------------------- K13 spanning tree
+def scipy_max_spanning_tree(S, D, w):
+    """The reference's route (tree_BI.py:32-59): minimum spanning tree of the negated weights."""
+    from scipy.sparse import csgraph
+    W = np.asarray(w, dtype=float).reshape(S, D)
+    graph = sp.bmat([[None, sp.csr_matrix(-W)], [sp.csr_matrix((D, S)), None]], format="csr")
+    tree = csgraph.minimum_spanning_tree(graph).tocoo()
+    return np.sort(tree.row.astype(np.int64) * D + (tree.col.astype(np.int64) - S))
+
+
+@pytest.mark.parametrize("S,D,seed", [(12, 15, 0), (1, 9, 1), (9, 1, 2), (64, 200, 3), (784, 784, 4)])
+def test_spanning_tree_matches_scipy_on_distinct_weights(ctx, S, D, seed):
+    rng = np.random.default_rng(seed)
+    w = rng.permutation(S * D).astype(np.float64) + 1.0 + rng.random(S * D) * 0.5      # distinct, positive
+    w *= 1e-6
+    got = ctx.spanning_tree_ot(S, D, ctx.to_device(w))
+    assert got.dtype == np.int64 and got.size == S + D - 1
+    assert np.array_equal(got, scipy_max_spanning_tree(S, D, w))
+
+
+def test_spanning_tree_golden_and_sinkhorn_like_plan(ctx, g4):
+    S, D = g4["M"].shape
+    assert np.array_equal(ctx.spanning_tree_ot(S, D, ctx.to_device(g4["ind"])), g4["tree_edges"])    # reference golden
+    inst = workloads.config3()
+    ind = N.ot_flow_indicators(inst.x, inst.s, inst.d)
+    got = ctx.spanning_tree_ot(784, 784, ctx.to_device(ind))
+    want = scipy_max_spanning_tree(784, 784, ind)
+    assert got.size == 1567
+    # equal weights may be resolved differently: compare the total weight, and the trees when all chosen weights differ
+    assert ind[got].sum() == pytest.approx(ind[want].sum(), rel=1e-13)
+    if np.unique(ind[want]).size == want.size:
+        assert np.array_equal(got, want)
+
+
+def test_spanning_tree_zero_weights_ties_and_nan(ctx):
+    # two components: suppliers {0,1} x demanders {0}, supplier {2} x demanders {1,2}; zeros and NaN are not edges
+    w = np.array([[3.0, 0.0, 0.0],
+                  [2.0, 0.0, np.nan],
+                  [0.0, 5.0, 1.0]])
+    got = ctx.spanning_tree_ot(3, 3, ctx.to_device(w.ravel()))
+    assert np.array_equal(got, [0, 3, 7, 8])                       # a forest with 4 < S + D - 1 arcs
+    # all weights equal: the smaller arc index wins -> first row and first column
+    got = ctx.spanning_tree_ot(4, 5, ctx.to_device(np.full(20, 0.25)))
+    assert got.size == 8
+    tree = np.zeros(20, dtype=bool)
+    tree[got] = True
+    T = tree.reshape(4, 5)
+    assert T[0].all() and T[:, 0].all()
+    assert ctx.spanning_tree_ot(3, 0, ctx.to_device(np.zeros(1))).size == 0

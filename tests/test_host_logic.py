@@ -153,9 +153,11 @@ def test_ot_manager_host_parts_and_tree_basis(g4):
     ot = OptTransport(g4["s"].copy(), g4["d"].copy(), g4["M"].copy())
     mgr = OTManager(ot)
     mgr.get_mcf()
-    assert np.array_equal(tree_BI.max_weight_spanning_tree(ot, g4["ind"]), g4["tree_edges"])
-    basis, pushes = tree_BI.tree_basis_identify(mgr, g4["ind"])
-    assert np.array_equal(basis.vbasis, g4["tree_vb"].astype(int)) and pushes == int(g4["push_iter"])
+    # K14 + K15 are host steps; the spanning tree itself (K13) is a device kernel, checked in the GPU tests
+    vbasis, pushes = tree_BI.push_tree_to_bfs(mgr, g4["tree_edges"].astype(np.int64))
+    assert np.array_equal(vbasis, g4["tree_vb"].astype(int)) and pushes == int(g4["push_iter"])
+    from smart_crossover.output import Basis
+    basis = Basis(vbasis, np.concatenate([-np.ones(mgr.m - 1), np.array([0])]))
     assert np.array_equal(basis.cbasis, g4["tree_cb"].astype(int))
     mgr.add_free_variables(basis.vbasis == 0)                       # quirk Q10: boolean mask on the flat problem
     assert np.array_equal(np.flatnonzero(mgr.mask_sub_ot), np.flatnonzero(basis.vbasis == 0))
@@ -179,8 +181,8 @@ def test_tree_solver_rejects_disconnected_support():
     ot = OptTransport(np.array([0.5, 0.5]), np.array([0.5, 0.5]), np.ones((2, 2)))
     mgr = OTManager(ot)
     mgr.get_mcf()
-    with pytest.raises(ValueError):
-        tree_BI.tree_basis_identify(mgr, np.array([1.0, 0.0, 0.0, 1.0]))
+    with pytest.raises(ValueError):          # a 2-arc forest on 4 nodes: arcs (0,0) and (1,1)
+        tree_BI.push_tree_to_bfs(mgr, np.array([0, 3], dtype=np.int64))
 
 
 # ----------------------------------------------------------------------------- column generation driver

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""End-to-end network crossover at BASELINE sizes through the kept Python API (host memory in, basis out).
+
+    python tools/crossover_bench.py [--case c3_tnet|c3_cnet|c4_cnet|all] [--solver HGS] [--time-limit 600]
+
+Prints one JSON object per case: wall time of ``network_crossover`` (the reference's ``Output.runtime``
+definition: host set-up and bookkeeping + solver-reported solve times), how much of it the sub-problem
+solver took, how much the host-side arithmetic took (flow indicators, ranking, sub-problem assembly,
+pricing -- the part this repository moves to the GPU), the same arithmetic timed with the numpy/scipy
+oracle on one host core, and solver-independent certificates of the result.
+"""
+import argparse
+import io
+import json
+import os
+import sys
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
+
+import workloads  # noqa: E402
+
+
+def quiet(fn, *a, **kw):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        out = fn(*a, **kw)
+    return out, buf.getvalue()
+
+
+class SolveClock:
+    """Wraps NetworkManager.solve_subproblem to record what the solver itself reports."""
+
+    def __init__(self, manager_cls):
+        self.cls = manager_cls
+        self.orig = manager_cls.solve_subproblem
+        self.seconds, self.wall, self.calls, self.sizes = 0.0, 0.0, 0, []
+
+    def __enter__(self):
+        clock = self
+
+        def wrapped(mgr, solver, settings):
+            t0 = time.perf_counter()
+            out = clock.orig(mgr, solver, settings)
+            clock.wall += time.perf_counter() - t0
+            clock.seconds += out.runtime.total_seconds()
+            clock.calls += 1
+            clock.sizes.append(int(out.x.size))
+            return out
+
+        self.cls.solve_subproblem = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.solve_subproblem = self.orig
+
+
+def oracle_seconds_ot(inst):
+    """CPU time of the host arithmetic the OT path does once per crossover (oracle restatement)."""
+    from oracle import net_path as N
+    t0 = time.perf_counter()
+    ind = N.ot_flow_indicators(inst.x, inst.s, inst.d)
+    N.rank_desc(ind)
+    S, D = inst.M.shape
+    y = np.zeros(S + D)
+    N.ot_reduced_cost(inst.M, y)
+    return time.perf_counter() - t0
+
+
+def oracle_seconds_mcf(inst):
+    from oracle import net_path as N
+    t0 = time.perf_counter()
+    ind, _ = N.mcf_flow_indicators(inst.A, inst.x, inst.u)
+    N.rank_desc(ind)
+    N.mcf_reduced_cost(inst.A, inst.c, np.zeros(inst.A.shape[0]), np.full(inst.A.shape[1], -1))
+    return time.perf_counter() - t0
+
+
+def run_ot(method, solver, limit):
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.network_methods.net_manager import OTManager
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.config3()
+    ot = OptTransport(inst.s.copy(), inst.d.copy(), inst.M.copy())
+    S, D = inst.M.shape
+    st = SolverSettings(log_console=0, timeLimit=limit)
+    with SolveClock(OTManager) as clk:
+        t0 = time.perf_counter()
+        out, text = quiet(network_crossover, inst.x, ot=ot, method=method, solver=solver, solver_settings=st)
+        wall = time.perf_counter() - t0
+    X = (out.x.reshape(S + 1, D + 1)[:S, :D] if method == "cnet_ot" else out.x.reshape(S, D))
+    rec = {
+        "case": f"c3_{method}", "problem": f"OT {S}x{D} (n = {S * D}), Manhattan grid cost", "solver": solver,
+        "wall_ms": wall * 1e3, "runtime_reported_ms": out.runtime.total_seconds() * 1e3,
+        "solver_ms": clk.wall * 1e3, "host_path_ms": (wall - clk.wall) * 1e3, "subproblem_solves": clk.calls,
+        "subproblem_columns": clk.sizes, "simplex_iterations": int(out.iter_count),
+        "cg_rounds": text.count("CG iteration"), "objective": float(out.obj_val),
+        "marginal_violation": float(max(np.abs(X.sum(axis=1) - inst.s).max(), np.abs(X.sum(axis=0) - inst.d).max())),
+        "plan_cost": float((X * inst.M).sum()), "nonzeros_in_plan": int(np.count_nonzero(X > 1e-12)),
+        "oracle_host_arithmetic_ms_one_pass": oracle_seconds_ot(inst) * 1e3,
+    }
+    return rec
+
+
+def run_mcf(solver, limit):
+    from smart_crossover.formats import MinCostFlow
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.network_methods.net_manager import MCFManagerStd
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.config4()
+    mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
+    V, E = inst.A.shape
+    st = SolverSettings(log_console=0, timeLimit=limit)
+    with SolveClock(MCFManagerStd) as clk:
+        t0 = time.perf_counter()
+        out, text = quiet(network_crossover, inst.x, mcf=mcf, method="cnet_mcf", solver=solver, solver_settings=st)
+        wall = time.perf_counter() - t0
+    x = out.x[:E]
+    rec = {
+        "case": "c4_cnet_mcf", "problem": f"MCF V = {V}, E = {E}", "solver": solver,
+        "wall_ms": wall * 1e3, "runtime_reported_ms": out.runtime.total_seconds() * 1e3,
+        "solver_ms": clk.wall * 1e3, "host_path_ms": (wall - clk.wall) * 1e3, "subproblem_solves": clk.calls,
+        "subproblem_columns": clk.sizes, "simplex_iterations": int(out.iter_count),
+        "cg_rounds": text.count("CG iteration"), "objective": float(out.obj_val),
+        "flow_conservation_violation": float(np.abs(inst.A @ x - inst.b).max()),
+        "bound_violation": float(max((-x).max(), (x - inst.u).max(), 0.0)),
+        "artificial_flow": float(np.abs(out.x[E:]).max()) if out.x.size > E else 0.0,
+        "cost": float(inst.c @ x),
+        "oracle_host_arithmetic_ms_one_pass": oracle_seconds_mcf(inst) * 1e3,
+    }
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="all")
+    ap.add_argument("--solver", default="HGS")
+    ap.add_argument("--time-limit", type=int, default=600)
+    args = ap.parse_args()
+    cases = ["c3_tnet", "c3_cnet", "c4_cnet"] if args.case == "all" else [args.case]
+    for case in cases:
+        t0 = time.time()
+        if case == "c3_tnet":
+            rec = run_ot("tnet", args.solver, args.time_limit)
+        elif case == "c3_cnet":
+            rec = run_ot("cnet_ot", args.solver, args.time_limit)
+        elif case == "c4_cnet":
+            rec = run_mcf(args.solver, args.time_limit)
+        else:
+            raise SystemExit(f"unknown case {case}")
+        rec["total_tool_seconds"] = time.time() - t0
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
