@@ -97,8 +97,8 @@ def push_tree_to_bfs(ot_manager: OTManager, tree: np.ndarray) -> Tuple[np.ndarra
             assert T[I2, J1] > 0 and T[I1, J2] > 0
             assert T[I2, J2] == 0
             candidates = (-T[I1, J1], T[I1, J2], T[I2, J1])
-            which = int(np.argmin(candidates))
-            theta = candidates[which]
+            theta = min(candidates)
+            which = candidates.index(theta)          # first minimum, as np.argmin
             T[I1, J1] += theta
             T[I2, J1] -= theta
             T[I1, J2] -= theta

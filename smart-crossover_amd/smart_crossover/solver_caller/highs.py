@@ -156,14 +156,16 @@ class HgsCaller(SolverCaller):
     def add_warm_start_basis(self, basis: Basis) -> None:
         hc = self.hc
         st = hc.HighsBasisStatus
-        col_map = {0: st.kBasic, -1: st.kLower, -2: st.kUpper, -3: st.kZero}
         hb = hc.HighsBasis()
-        hb.col_status = [col_map.get(int(v), st.kLower) for v in basis.vbasis]
-        inf = hc.kHighsInf
-        rows = []
-        for v, up in zip(basis.cbasis, self._row_upper):
-            rows.append(st.kBasic if int(v) == 0 else (st.kUpper if up < inf else st.kLower))
-        hb.row_status = rows
+        # codes 0 / -1 / -2 / -3 -> table slots 0..3 (anything else: at lower); one C-level pass each
+        col_table = (st.kBasic, st.kLower, st.kUpper, st.kZero)
+        vb = np.asarray(basis.vbasis).astype(np.int64)
+        slot = np.where((vb <= 0) & (vb >= -3), -vb, 1)
+        hb.col_status = list(map(col_table.__getitem__, slot.tolist()))
+        row_table = (st.kBasic, st.kUpper, st.kLower)
+        cb = np.asarray(basis.cbasis).astype(np.int64)
+        rslot = np.where(cb == 0, 0, np.where(self._row_upper < hc.kHighsInf, 1, 2))
+        hb.row_status = list(map(row_table.__getitem__, rslot.tolist()))
         hb.valid = True
         hb.alien = True      # let HiGHS repair a basis that is not exactly m x m non-singular
         self.h.setBasis(hb)
@@ -285,7 +287,12 @@ class HgsCaller(SolverCaller):
         if not hb.valid:
             return None
         st = self.hc.HighsBasisStatus
-        col_code = {st.kBasic: 0, st.kLower: -1, st.kUpper: -2, st.kZero: -3, st.kNonbasic: -1}
-        vb = np.array([col_code[s] for s in hb.col_status], dtype=int)
-        cb = np.array([0 if s == st.kBasic else -1 for s in hb.row_status], dtype=int)
-        return Basis(vb, cb)
+        # enum -> int in one C-level pass, then a table lookup (codes of output.py: 0 / -1 / -2 / -3)
+        code = np.full(1 + max(int(v) for v in (st.kBasic, st.kLower, st.kUpper, st.kZero, st.kNonbasic)), -1)
+        for status, value in ((st.kBasic, 0), (st.kLower, -1), (st.kUpper, -2), (st.kZero, -3), (st.kNonbasic, -1)):
+            code[int(status)] = value
+        cols, rows = hb.col_status, hb.row_status
+        vb = code[np.fromiter(map(int, cols), dtype=np.int64, count=len(cols))]
+        rb = np.fromiter(map(int, rows), dtype=np.int64, count=len(rows))
+        cb = np.where(rb == int(st.kBasic), 0, -1)
+        return Basis(vb.astype(int), cb.astype(int))
