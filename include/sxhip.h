@@ -266,6 +266,14 @@ int sx_projector_norm_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, con
 int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                      const double *c, double tol, int maxiter, double *proj_cols, double *proj_rows,
                      sx_cg_result *result);
+/* same with a cost on the slack columns as well (cs[m], read on the rows where xs != 0; NULL = zero):
+ * v = [xa .* c ; xs .* cs], proj_rows[m] = xs .* (cs - z).  Needed by the free-variable branch of
+ * get_projector_Xc (lp_methods/algorithms.py:174-180), whose adjusted cost c - A_1^T A_2 t is non-zero on
+ * slack columns; the free columns themselves enter with a large scale xa[j] and zero cost, which is the
+ * penalty form of the reference's QP  min ||x - v||^2  s.t.  A_1 X_1 x + A_2 f = 0. */
+int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                         const double *c, const double *cs, double tol, int maxiter, double *proj_cols,
+                         double *proj_rows, sx_cg_result *result);
 /* get_x_perturb_val (lp_methods/algorithms.py:196-202): min(x-l, u-x), free columns -> x; with
  * apply_floor != 0 also the two overwrites of perturb_c (:131-132): values < 1e-6 -> 1e-6, free
  * columns -> 1 */

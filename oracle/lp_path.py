@@ -247,12 +247,49 @@ def scale_factor_from_projection(proj: np.ndarray, n_std: int) -> float:
     return float(np.linalg.norm(proj) / n_std)
 
 
+def projector_qp_exact(Y, v: np.ndarray, A_f=None) -> np.ndarray:
+    """What apply_projector_qp defines (lp_methods/algorithms.py:240-265):
+    argmin ||x - v||^2  s.t.  Y x (+ A_f f) = 0, stated through its KKT system and solved densely by
+    least squares.  Small inputs only.  **Parity unpinned**: the reference solves this QP inside Gurobi
+    (BarQCPConvTol = 1e-1), which cannot run here; this is the exact minimiser of the same problem."""
+    Y = np.asarray(Y.todense()) if sp.issparse(Y) else np.asarray(Y, dtype=float)
+    m = Y.shape[0]
+    if A_f is None:
+        K, rhs = Y @ Y.T, Y @ v
+    else:
+        F = np.asarray(A_f.todense()) if sp.issparse(A_f) else np.asarray(A_f, dtype=float)
+        nf = F.shape[1]
+        K = np.block([[Y @ Y.T, F], [F.T, np.zeros((nf, nf))]])
+        rhs = np.concatenate([Y @ v, np.zeros(nf)])
+    lam = np.linalg.lstsq(K, rhs, rcond=None)[0][:m]
+    return v - Y.T @ lam
+
+
+def projector_Xc_free(A, b, c, l, u, sense, x_real):
+    """Free-variable branch of get_projector_Xc (lp_methods/algorithms.py:173-180): the cost of the
+    free columns is first removed by a least-squares step (cg on A_2^T A_2 there; solved densely here),
+    then X_1 c' is projected with the free columns as unweighted extra unknowns.  Returns the projection
+    over the non-free standard columns (structural ones in order, then the slack columns)."""
+    free = free_index(l, u)
+    n = A.shape[1]
+    xx = standard_x(A, b, sense, x_real)
+    c_std = standard_c(c, sense)
+    A_std = sp.csr_matrix(standard_A(A, sense))
+    nonfree = np.setdiff1d(np.arange(A_std.shape[1]), free)          # formats.py:34-36
+    A1, A2 = A_std[:, nonfree], sp.csr_matrix(A)[:, free]
+    G = (A2.T @ A2).toarray()
+    trans = np.linalg.lstsq(G, c_std[free], rcond=None)[0]
+    c_nonfree = c_std[nonfree] - A1.T @ (A2 @ trans)
+    assert nonfree.size == n - free.size + int(np.count_nonzero(np.asarray(sense) == "<"))
+    return projector_qp_exact(A1 @ sp.diags(xx[nonfree]), xx[nonfree] * c_nonfree, A2)
+
+
 def projector_Xc(A, b, c, l, u, sense, x_real, tol=1e-8, maxiter=1000, explicit=True):
-    """lp_methods/algorithms.py:162-172, no-free-variable branch (quirk Q4: the slack
-    block is built from the clipped ``x_real``).  The branch with free
-    variables goes through a Gurobi QP in the reference and is unpinned."""
+    """lp_methods/algorithms.py:162-180 (quirk Q4: the slack block is built from the clipped
+    ``x_real``).  With free variables the reference goes through a Gurobi QP: see
+    ``projector_Xc_free`` (exact minimiser, parity unpinned)."""
     if free_index(l, u).size:
-        raise NotImplementedError("free-variable branch needs the reference's QP solver (unpinned)")
+        return projector_Xc_free(A, b, c, l, u, sense, x_real), 0
     xx = standard_x(A, b, sense, x_real)
     c_std = standard_c(c, sense)
     if explicit:

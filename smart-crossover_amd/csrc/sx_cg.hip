@@ -231,15 +231,33 @@ __global__ __launch_bounds__(SX_WG) void k_cg_proj_cols(int64_t n, const double 
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// r[i] += xs[i]^2 * cs[i];  partial = sum r[i]^2 (only when the slack columns carry a cost)
+__global__ __launch_bounds__(SX_WG) void k_cg_slack_cost(int64_t m, const double *__restrict__ xs,
+                                                         const double *__restrict__ cs, double *__restrict__ r,
+                                                         double *__restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double s = xs[i];
+        const double ri = r[i] + (s * s) * cs[i];
+        r[i] = ri;
+        acc += ri * ri;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(SX_WG) void k_cg_proj_rows(int64_t m, const double *__restrict__ xs,
+                                                        const double *__restrict__ cs,
                                                         const double *__restrict__ z,
                                                         double *__restrict__ partial,
                                                         double *__restrict__ proj_out) {
     double acc = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
          i += static_cast<int64_t>(gridDim.x) * SX_WG) {
-        const double pi = xs[i] * z[i];
-        if (proj_out) proj_out[i] = -pi; // slack block of proj is -xs .* z (slack costs are zero)
+        // slack block of proj: xs .* (cs - z); without slack costs it is -xs .* z
+        const double pi = cs ? xs[i] * (cs[i] - z[i]) : -(xs[i] * z[i]);
+        if (proj_out) proj_out[i] = pi;
         acc += pi * pi;
     }
     const double tot = block_sum(acc);
@@ -275,6 +293,12 @@ inline int grid_for(const sx_ctx *ctx, int64_t ntiles) {
 SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                             const double *c, double tol, int maxiter, double *proj_cols,
                             double *proj_rows, sx_cg_result *result) {
+    return sx_projector_std_dev(ctx, A, xa, xs, c, nullptr, tol, maxiter, proj_cols, proj_rows, result);
+}
+
+SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
+                                const double *c, const double *cs, double tol, int maxiter,
+                                double *proj_cols, double *proj_rows, sx_cg_result *result) {
     SX_ENTER(ctx);
     SX_REQUIRE(A != nullptr && result != nullptr, "matrix or result is NULL");
     SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the projector needs both layouts of A");
@@ -313,7 +337,12 @@ SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, c
     hipLaunchKernelGGL(k_cg_scale_c, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, w);
     hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
                        A->csr_ptr, A->csr_idx, A->csr_val, w, xs, static_cast<const double *>(nullptr), r, ppq);
-    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(SX_WG), 0, s, st, m, ppq, gA, r, p, z);
+    int n_rho0 = gA;
+    if (cs) { // slack columns carry a cost: b += xs^2 .* cs, rho0 recomputed from the completed b
+        hipLaunchKernelGGL(k_cg_slack_cost, dim3(gv), dim3(SX_WG), 0, s, m, xs, cs, r, ppq);
+        n_rho0 = gv;
+    }
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(SX_WG), 0, s, st, m, ppq, n_rho0, r, p, z);
     CgState host;
     SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
@@ -388,7 +417,7 @@ SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, c
     hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
                        A->csc_ptr, A->csc_idx, A->csc_val, z, w, atz);
     hipLaunchKernelGGL(k_cg_proj_cols, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, atz, ppq, proj_cols);
-    hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, z, prr, proj_rows);
+    hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, cs, z, prr, proj_rows);
     hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, st, ppq, gv, prr, gv);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));

@@ -216,12 +216,15 @@ class Context:
                                            result.ptr))
         return result
 
-    def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000, proj_cols=None, proj_rows=None) -> "_l.CgResult":
+    def projector_norm(self, A, xa, xs, c, tol=1e-8, maxiter=1000, proj_cols=None, proj_rows=None,
+                       cs=None) -> "_l.CgResult":
         """K4 (blocking): ||(I - Y^T (YY^T)^+ Y) v|| by matrix-free CG; device pointers in; the
-        projection itself lands in proj_cols[n] / proj_rows[m] when given."""
+        projection itself lands in proj_cols[n] / proj_rows[m] when given.  ``cs`` (m) is an optional
+        cost on the slack columns."""
         res = _l.CgResult()
-        _l.check(self._lib.sx_projector_dev(self.handle, A.handle, _ptr(xa), _ptr(xs), _ptr(c), float(tol),
-                                            int(maxiter), _ptr(proj_cols), _ptr(proj_rows), C.byref(res)))
+        _l.check(self._lib.sx_projector_std_dev(self.handle, A.handle, _ptr(xa), _ptr(xs), _ptr(c), _ptr(cs),
+                                                float(tol), int(maxiter), _ptr(proj_cols), _ptr(proj_rows),
+                                                C.byref(res)))
         return res
 
     def simplex(self, A, b, c, l, u, row_is_lt, vbasis=None, cbasis=None, max_iter=0, feas_tol=1e-7, opt_tol=1e-7,

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "sx_argsort_desc_dev": (_int, [_vp, _i64, _vp, _vp]),
     "sx_price_ot_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _dbl, _vp, _vp]),
     "sx_projector_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, C.POINTER(CgResult)]),
+    "sx_projector_std_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, C.POINTER(CgResult)]),
     "sx_x_real_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "sx_mask_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),

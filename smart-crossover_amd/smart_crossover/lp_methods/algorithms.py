@@ -119,6 +119,55 @@ def _projector_device(dv: _Resident, xa, xs, c, tol: float, max_iter: int, want_
     return info, pc, pr
 
 
+FREE_COLUMN_WEIGHT = 100.0     # penalty scale of the free columns relative to the largest ordinary scale
+
+
+def _free_column_scale(A_cols_norm_max: float, A_free_norm_min: float, scale_max: float) -> float:
+    """Scale tau given to free columns in the penalty form of the reference's QP.  The minimiser of
+    ||x - v||^2 + ||f||^2 / tau^2 over {Y x + A_2 f = 0} tends to the QP's with an error of order
+    (||Y|| / (tau sigma_min(A_2)))^2; with tau = 100 x the largest ordinary column scale (corrected for
+    the ratio of column norms) that is ~1e-7 relative while CG still converges (1e4 x does not)."""
+    ratio = A_cols_norm_max / A_free_norm_min if A_free_norm_min > 0 else 1.0
+    return FREE_COLUMN_WEIGHT * max(scale_max, 1e-300) * max(1.0, ratio)
+
+
+def _projector_free_device(lp: GeneralLP, dv: _Resident, x_real, xs, want_vector: bool):
+    """Free-variable branch of get_projector_Xc (lp_methods/algorithms.py:173-180) on the device.
+
+    Reference: t = cg(A_2^T A_2, c_free); c' = c_std[nonfree] - A_1^T A_2 t; then the Gurobi QP
+    min ||x - X_1 c'||^2 s.t. A_1 X_1 x + A_2 f = 0.  Here the QP is the limit of the ordinary projector
+    in which the free columns carry a large scale tau and zero cost, so the same matrix-free CG (K4)
+    serves; only the adjusted cost is new: its structural part is c - A^T g with g = A_2 t (one column
+    scoring pass, K1), its slack part -g on the '<' rows.  Parity with the reference is unpinned (no
+    Gurobi); tests compare with the exact minimiser of the QP (oracle.projector_Xc_free)."""
+    from scipy.sparse.linalg import cg as _cg
+    ctx, m, n = dv.ctx, dv.m, dv.n
+    free = lp.get_free_ind()
+    A = sp.csc_matrix(lp.A)
+    A2 = A[:, free]
+    trans, _ = _cg(A2.T @ A2, np.asarray(lp.c, dtype=np.float64)[free], rtol=1e-8, atol=0.0, maxiter=1000)
+    g = A2 @ trans
+    g_dev = ctx.to_device(np.ascontiguousarray(g, dtype=np.float64))
+    c_adj_dev = ctx.empty(n, np.float64)
+    ctx.score_columns(dv.res.A, g_dev, dv.c, None, None, None, 0.0, c_adj_dev, None)      # c - A^T g
+    c_adj = c_adj_dev.download()
+    c_adj[free] = 0.0
+    xa = x_real.download()
+    xs_host = xs.download()
+    col_norm = np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).ravel())
+    tau = _free_column_scale(float(col_norm.max(initial=0.0)), float(col_norm[free].min()),
+                             max(float(np.delete(xa, free).max(initial=0.0)), float(xs_host.max(initial=0.0))))
+    xa[free] = tau
+    cs = np.where(np.asarray(lp.sense) == "<", -g, 0.0)
+    pc, pr = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+    info = ctx.projector_norm(dv.res.A, ctx.to_device(xa), xs, ctx.to_device(c_adj), 1e-8, 1000, pc, pr,
+                              cs=ctx.to_device(cs))
+    # the free block of the penalised projection is f / tau, not part of the QP's x: leave it out
+    proj = np.concatenate([np.delete(pc.download(), free), pr.download()[np.asarray(lp.sense) == "<"]])
+    info.proj_norm = float(np.linalg.norm(proj))
+    return info, proj, None
+
+
 def _scaled_slack(dv: _Resident, x_real_dev):
     """Slack block of the standard-form vector built from x_real (quirk Q4): b_< - A_< x_real on the
     '<' rows, 0 on the '=' rows."""
@@ -138,14 +187,13 @@ def _perturb_c_device(lp: GeneralLP, dv: _Resident, is_feas: bool):
     if is_feas:
         ctx.perturb_cost(n, None, None, None, dv.c, xi, 0.0, True, c_pt)
         return c_pt, {}
-    if lp.get_free_ind().size:
-        raise NotImplementedError(
-            "perturb_c with free variables: the reference routes this branch through a Gurobi QP "
-            "(lp_methods/algorithms.py:174-180); no pinned counterpart exists yet")
     x_real = ctx.empty(n, np.float64)
     ctx.x_real(n, dv.x, dv.l, dv.u, x_real, True)
     xs = _scaled_slack(dv, x_real)
-    info, _, _ = _projector_device(dv, x_real, xs, dv.c, 1e-8, 1000, False)
+    if lp.get_free_ind().size:
+        info, _, _ = _projector_free_device(lp, dv, x_real, xs, False)
+    else:
+        info, _, _ = _projector_device(dv, x_real, xs, dv.c, 1e-8, 1000, False)
     scale_factor = get_scale_factor_from_norm(info.proj_norm, n + dv.res.n_lt)
     ctx.perturb_cost(n, dv.x, dv.l, dv.u, dv.c, xi, scale_factor, False, c_pt)
     return c_pt, dict(proj_norm=info.proj_norm, scale_factor=scale_factor, cg_iters=int(info.iters),
@@ -212,11 +260,13 @@ def _assemble_std(lp: GeneralLP, proj_cols, proj_rows) -> np.ndarray:
 
 def get_projector_Xc(lp: GeneralLP, x: np.ndarray) -> np.ndarray:
     """[I - (A X)^T (A X X A^T)^+ (A X)] X c in standard form, X = diag(standard_x(x))
-    (lp_methods/algorithms.py:162-180, branch without free variables)."""
-    if lp.get_free_ind().size:
-        raise NotImplementedError("get_projector_Xc with free variables needs the reference's Gurobi QP branch")
+    (lp_methods/algorithms.py:162-180).  With free variables the result covers the non-free standard
+    columns only, like the reference's QP solution (see _projector_free_device)."""
     dv = _Resident(lp, x)
     xs = _scaled_slack(dv, dv.x)
+    if lp.get_free_ind().size:
+        _, proj, _ = _projector_free_device(lp, dv, dv.x, xs, True)
+        return proj
     _, pc, pr = _projector_device(dv, dv.x, xs, dv.c, 1e-8, 1000, True)
     return _assemble_std(lp, pc, pr)
 
@@ -240,11 +290,27 @@ def apply_projector(Y, v, tol: float = 1e-8, max_iter: int = 1000) -> np.ndarray
 def apply_projector_qp(A: sp.csr_matrix, v: np.ndarray, A_f: Optional[sp.csr_matrix] = None) -> np.ndarray:
     """Projection of v onto {x : A x = 0} (lp_methods/algorithms.py:240-265).  The reference solves a
     least-squares QP with Gurobi (BarQCPConvTol 1e-1); here it is the same CG projector as
-    ``apply_projector`` (own counterpart, parity unpinned: no Gurobi).  The variant with free columns
-    ``A_f`` is not available."""
-    if A_f is not None:
-        raise NotImplementedError("apply_projector_qp with free columns needs the reference's Gurobi QP")
-    return apply_projector(A, v)
+    ``apply_projector`` (own counterpart, parity unpinned: no Gurobi).  Free columns ``A_f`` (the
+    constraint becomes A x + A_f f = 0) enter the same projector with a large scale and zero cost, the
+    penalty form of the QP (see _projector_free_device)."""
+    if A_f is None:
+        return apply_projector(A, v)
+    from smart_crossover.hip.device import default_context
+    ctx = default_context()
+    A, A_f = sp.csr_matrix(A), sp.csr_matrix(A_f)
+    m, n = A.shape
+    nf = A_f.shape[1]
+    both = sp.hstack([A, A_f], format="csr")
+    col_norm = np.sqrt(np.asarray(both.multiply(both).sum(axis=0)).ravel())
+    tau = _free_column_scale(float(col_norm[:n].max(initial=0.0)), float(col_norm[n:].min(initial=np.inf)), 1.0)
+    dY = ctx.matrix(both)
+    pc = ctx.empty(n + nf, np.float64)
+    ctx.projector_norm(dY, ctx.to_device(np.concatenate([np.ones(n), np.full(nf, tau)])), ctx.to_device(np.zeros(m)),
+                       ctx.to_device(np.concatenate([np.asarray(v, dtype=np.float64), np.zeros(nf)])), 1e-8, 1000,
+                       pc, None)
+    out = pc.download()[:n]
+    dY.free()
+    return out
 
 
 def get_projector_c(lp: GeneralLP) -> np.ndarray:

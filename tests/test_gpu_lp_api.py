@@ -150,3 +150,59 @@ def test_run_perturb_algorithm_end_to_end(case):
         assert out.x.size <= lp.c.size
     else:
         certificates(lp, out, ref.obj_val)
+
+
+# ----------------------------------------------------------------------------- free variables
+def lp_with_free_columns(m=40, n=120, nf=6, seed=3):
+    from smart_crossover.formats import GeneralLP
+    inst = workloads.sparse_lp(m, n, 6, seed=seed, frac_lt=0.5, frac_upper=0.3, stratified=False)
+    rng = np.random.default_rng(seed + 100)
+    free = np.sort(rng.choice(n, nf, replace=False))
+    l, u = inst.l.copy(), inst.u.copy()
+    l[free], u[free] = -np.inf, np.inf
+    x = inst.x.copy()
+    x[free] = rng.standard_normal(nf)                                   # free columns may sit anywhere
+    lp = GeneralLP(inst.A, inst.b, inst.c, l, u, inst.sense)
+    return lp, x, inst.y, free
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_projector_with_free_variables_matches_the_exact_qp(seed):
+    """Free-variable branch (lp_methods/algorithms.py:173-180): the reference's QP runs inside Gurobi
+    (parity unpinned); the device result must match the exact minimiser of that QP."""
+    from smart_crossover.lp_methods import algorithms as alg
+    lp, x, _, free = lp_with_free_columns(seed=seed)
+    xr = L.x_perturb_val(x, lp.l, lp.u)
+    want = L.projector_Xc_free(lp.A, lp.b, lp.c, lp.l, lp.u, lp.sense, xr)
+    got = alg.get_projector_Xc(lp, xr)
+    assert got.shape == want.shape == (lp.c.size - free.size + int(np.count_nonzero(lp.sense == "<")),)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.linalg.norm(want))
+    assert np.linalg.norm(got) == pytest.approx(np.linalg.norm(want), rel=1e-5)
+    # perturb_c end to end: same scale factor -> same perturbed cost; free columns are not perturbed
+    want_c, info = L.perturbed_cost_full(lp.A, lp.b, lp.c, lp.l, lp.u, lp.sense, x, False)
+    got_c = alg.perturb_c(lp, x, False)
+    # compare the perturbations themselves (c + p can cancel): they scale with the projection norm
+    np.testing.assert_allclose(got_c - lp.c, want_c - lp.c, rtol=2e-5, atol=0)
+    assert np.array_equal(got_c[free], lp.c[free]) and info["sf"] > 0
+    # and the whole sub-problem construction runs with free columns present
+    mgr, _ = quiet(alg.get_perturb_problem, lp, x, np.zeros(lp.b.size), 1e-3, 1e-3, False)
+    assert mgr.lp_sub.c.size <= lp.c.size
+
+
+def test_apply_projector_qp_with_free_block():
+    from smart_crossover.lp_methods import algorithms as alg
+    rng = np.random.default_rng(12)
+    A = sp.random(25, 70, density=0.2, random_state=5, format="csr")
+    A.data = rng.uniform(-1, 1, A.nnz)
+    A_f = sp.random(25, 4, density=0.5, random_state=6, format="csr")
+    A_f.data = rng.uniform(-2, 2, A_f.nnz)
+    v = rng.standard_normal(70)
+    want = L.projector_qp_exact(A, v, A_f)
+    got = alg.apply_projector_qp(A, v, A_f)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.linalg.norm(want))
+    # the defining property: A x lies in the range of A_f, and x is no farther from v than v's own projection
+    resid = A @ got
+    coef = np.linalg.lstsq(A_f.toarray(), -resid, rcond=None)[0]
+    assert np.linalg.norm(resid + A_f @ coef) < 1e-5 * np.linalg.norm(v)
+    plain = alg.apply_projector_qp(A, v)
+    assert np.linalg.norm(got - v) <= np.linalg.norm(plain - v) * (1 + 1e-9)
