@@ -142,7 +142,14 @@ def main():
     structure = args.structure or ("staircase" if args.workload == "c5" else "uniform")
     if m % k or k % world:
         raise SystemExit(f"workload {args.workload}: world={world} must divide nnz/col={k}")
-    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5, structure=structure)
+    if structure == "staircase":
+        # weak scaling: rows and columns of the global LP grow together (8 row regions and m rows per
+        # rank), so every rank's column and row block keeps the shape of the single-GPU problem
+        m = m * world
+        sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5, structure=structure,
+                                regions=workloads.STAIR_REGIONS * world)
+    else:
+        sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, k=k, seed=5, structure=structure)
     desc = f"{desc}; row structure: {structure}"
     if rank == 0:
         log(f"[bench] generated shard in {time.time() - t0:.1f}s: col block {sh.col_block.shape} nnz={sh.col_block.nnz}, "

@@ -45,7 +45,12 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     m, n_block = 8000, 20000
-    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, structure=os.environ.get("SX_STRUCTURE", "staircase"))
+    structure = os.environ.get("SX_STRUCTURE", "staircase")
+    extra = {}
+    if structure == "staircase-weak":        # bench.py's weak-scaling layout: 8 row regions and m rows per rank
+        structure, m = "staircase", m * world
+        extra = {"regions": workloads.STAIR_REGIONS * world}
+    sh = workloads.lp_shard(rank, world, m=m, n_block=n_block, structure=structure, **extra)
     code, flag, record, counts, s_d = local_pass(sh)
 
     ex = D.Exchange(dist)
@@ -63,8 +68,7 @@ def main():
     if rank == 0:
         # single-process statement of the same global problem
         import scipy.sparse as sp
-        shards = [workloads.lp_shard(r, world, m=m, n_block=n_block, structure=os.environ.get("SX_STRUCTURE", "staircase"))
-                  for r in range(world)]
+        shards = [workloads.lp_shard(r, world, m=m, n_block=n_block, structure=structure, **extra) for r in range(world)]
         A = sp.vstack([s.row_block for s in shards]).tocsr()
         assert (sp.hstack([s.col_block for s in shards]).tocsr() != A).nnz == 0
         full = L.scoring_pass(A, np.concatenate([s.b for s in shards]), np.concatenate([s.c for s in shards]),

@@ -17,7 +17,7 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("structure", ["staircase", "uniform"])
+@pytest.mark.parametrize("structure", ["staircase", "staircase-weak", "uniform"])
 def test_two_rank_scoring_matches_single_process(tmp_path, structure):
     out = tmp_path / "result.json"
     port = free_port()

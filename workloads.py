@@ -284,28 +284,28 @@ def _uniform_blocks(rank, world, m, n_block, k, seed):
     return col_block, row_block
 
 
-STAIR_REGIONS = 8     # row regions; every rank owns 8/world of them
+STAIR_REGIONS = 8     # row regions of the default global LP; every rank owns 8/world of them
 
 
-def _stair_geometry(m: int, window: int):
-    mr = m // STAIR_REGIONS                   # rows per region
+def _stair_geometry(m: int, window: int, regions: int = STAIR_REGIONS):
+    mr = m // regions                         # rows per region
     nl = max(1, mr // 100)                    # linking rows at the head of each region (1 %)
     ms = mr - nl                              # stage rows of the region
     W = max(6, min(window, ms // 4))
     return mr, nl, ms, W
 
 
-def _stair_linking(seed: int, q: int, n_block: int, nl: int):
+def _stair_linking(seed: int, q: int, n_block: int, nl: int, regions: int = STAIR_REGIONS):
     """Slot 7 of block q: one linking entry per column (region, row inside the region's linking rows, value)."""
     rng = np.random.default_rng([seed, q, 7])
-    region = rng.integers(0, STAIR_REGIONS, size=n_block, dtype=np.int32)
+    region = rng.integers(0, regions, size=n_block, dtype=np.int32)
     off = rng.integers(0, nl, size=n_block, dtype=np.int32)
     val = rng.uniform(-1.0, 1.0, size=n_block)
     val[np.abs(val) < 1e-3] = 0.5
     return region, off, val
 
 
-def _staircase_blocks(rank, world, m, n_block, k, seed, window):
+def _staircase_blocks(rank, world, m, n_block, k, seed, window, regions=STAIR_REGIONS):
     """Netlib-style structure (staircase / block-angular with linking rows), 8 entries per column:
     six in a window of W stage rows at the column's home position, one in the following window
     (the coupling to the next stage) and one in a linking row (1 % of the rows, shared by all
@@ -313,10 +313,10 @@ def _staircase_blocks(rank, world, m, n_block, k, seed, window):
     neighbouring rows, as in multi-period netlib models."""
     if k != 8:
         raise ValueError("the staircase generator places exactly 8 entries per column")
-    G = STAIR_REGIONS // world                # regions owned by this rank
+    G = regions // world                      # regions owned by this rank
     if n_block % G:
-        raise ValueError("n_block must be divisible by 8/world")
-    mr, nl, ms, W = _stair_geometry(m, window)
+        raise ValueError("n_block must be divisible by the number of regions per rank")
+    mr, nl, ms, W = _stair_geometry(m, window, regions)
     ws = W // 6
     per_region = n_block // G
     j = np.arange(n_block, dtype=np.int64)
@@ -336,7 +336,7 @@ def _staircase_blocks(rank, world, m, n_block, k, seed, window):
         v[np.abs(v) < 1e-3] = 0.5
         idx[:, t] = base + off
         val[:, t] = v
-    region, off7, v7 = _stair_linking(seed, rank, n_block, nl)
+    region, off7, v7 = _stair_linking(seed, rank, n_block, nl, regions)
     idx[:, 7] = region * mr + off7
     val[:, 7] = v7
     # ascending rows inside every column: the linking entry goes first when its region is not
@@ -355,7 +355,7 @@ def _staircase_blocks(rank, world, m, n_block, k, seed, window):
     cols = [np.repeat(np.arange(rank * n_block, (rank + 1) * n_block, dtype=np.int32), 7)]
     vals = [val[:, :7].ravel()]
     for q in range(world):
-        rg, of, vv = (region, off7, v7) if q == rank else _stair_linking(seed, q, n_block, nl)
+        rg, of, vv = (region, off7, v7) if q == rank else _stair_linking(seed, q, n_block, nl, regions)
         mine = (rg >= rank * G) & (rg < (rank + 1) * G)
         rows.append((rg[mine] * mr + of[mine] - r0).astype(np.int32))
         cols.append((np.flatnonzero(mine) + q * n_block).astype(np.int32))
@@ -367,19 +367,25 @@ def _staircase_blocks(rank, world, m, n_block, k, seed, window):
 
 
 def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_000, k: int = 8,
-             seed: int = 5, structure: str = "staircase", window: int = 4096) -> LPShard:
+             seed: int = 5, structure: str = "staircase", window: int = 4096,
+             regions: int = STAIR_REGIONS) -> LPShard:
     """Rank-local part of one global m x (world*n_block) LP (weak scaling): column block ``rank``
     in CSC and row block ``rank`` (m/world rows) in CSR, generated without generating the other
     ranks' blocks.  ``structure`` is "staircase" (netlib-style, default) or "uniform" (no
-    locality).  world must divide 8 (staircase) / k (uniform) and k must divide m."""
+    locality).  world must divide ``regions`` (staircase) / k (uniform) and k must divide m.
+
+    ``regions`` is the number of row regions of the global staircase LP.  With the default 8 the
+    row count m is shared by all ranks, so rows get denser as ranks (columns) are added; passing
+    ``regions = 8 * world`` together with ``m = world * m_1`` grows rows and columns together, which
+    keeps every rank's blocks shaped like the single-rank problem (row length, window width)."""
     if structure == "uniform":
         if k % world or m % k:
             raise ValueError("world must divide k and k must divide m")
         col_block, row_block = _uniform_blocks(rank, world, m, n_block, k, seed)
     elif structure == "staircase":
-        if STAIR_REGIONS % world or m % STAIR_REGIONS:
-            raise ValueError("world must divide 8 and 8 must divide m")
-        col_block, row_block = _staircase_blocks(rank, world, m, n_block, k, seed, window)
+        if regions % world or m % regions:
+            raise ValueError("world must divide the number of regions and that number must divide m")
+        col_block, row_block = _staircase_blocks(rank, world, m, n_block, k, seed, window, regions)
     else:
         raise ValueError("structure must be 'staircase' or 'uniform'")
     m_loc = row_block.shape[0]
