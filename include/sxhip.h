@@ -119,7 +119,10 @@ int sx_matrix_download_csr(const sx_matrix *A, int64_t *rowptr, int32_t *col, do
  *     s_d[j]  = c[j] - sum_i a_ij * y[i]      (entries in stored CSC order, product and sum
  *                                               rounded separately, running sum from +0.0)
  *     code[j] = SX_CODE_LOW * (x[j]-l[j] < gamma*s_d[j])  |  SX_CODE_UP * (u[j]-x[j] < gamma*(-s_d[j]))
- * y has m entries; c, x, l, u, s_d, code have n.  s_d or code may be NULL (output skipped). */
+ * y has m entries; c, x, l, u, s_d, code have n.  s_d or code may be NULL (output skipped).
+ * Unless the "window" option is 0, the first sx_score_columns_dev / sx_price_dev call on a matrix with
+ * m >= 4096 builds its window table (one kernel, a device allocation and a stream synchronisation):
+ * make that call outside hipGraph capture; later calls only enqueue. */
 int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
                          const double *x, const double *l, const double *u, double gamma,
                          double *s_d, uint8_t *code);

@@ -64,6 +64,7 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     sx_device_guard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->t_made)
         for (int i = 0; i < 8; ++i) {
             (void)hipEventDestroy(ctx->t0[i]);
@@ -119,19 +120,25 @@ SX_API int sx_ctx_device_info(sx_ctx *ctx, char *name, size_t name_len, int *cu_
     return SX_OK;
 }
 
-int sx_reserve(sx_ctx *ctx, size_t bytes) {
-    if (bytes <= ctx->ws_bytes) return SX_OK;
+static int reserve_block(sx_ctx *ctx, void **block, size_t *have, size_t bytes) {
+    if (bytes <= *have) return SX_OK;
     // the old block may still be in use by enqueued kernels
     SX_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->ws) SX_HIP(hipFree(ctx->ws));
-    ctx->ws = nullptr;
-    ctx->ws_bytes = 0;
+    if (*block) SX_HIP(hipFree(*block));
+    *block = nullptr;
+    *have = 0;
     size_t want = std::max(bytes, static_cast<size_t>(1) << 20);
     want = (want + 255) & ~static_cast<size_t>(255);
-    SX_HIP(hipMalloc(&ctx->ws, want));
-    ctx->ws_bytes = want;
+    SX_HIP(hipMalloc(block, want));
+    *have = want;
     return SX_OK;
 }
+
+int sx_reserve(sx_ctx *ctx, size_t bytes) { return reserve_block(ctx, &ctx->ws, &ctx->ws_bytes, bytes); }
+
+// second grow-only block for kernels that call helpers using the first one (the radix sort keeps its
+// double buffers here while sx_scan_exclusive works in ctx->ws)
+int sx_reserve2(sx_ctx *ctx, size_t bytes) { return reserve_block(ctx, &ctx->ws2, &ctx->ws2_bytes, bytes); }
 
 SX_API int sx_malloc(sx_ctx *ctx, size_t bytes, void **dev_out) {
     SX_ENTER(ctx);

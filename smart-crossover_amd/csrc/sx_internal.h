@@ -52,6 +52,8 @@ struct sx_ctx {
     // sx_reserve is called by the host-pointer wrappers and by the first use of each size)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    void *ws2 = nullptr; // second block (sx_reserve2)
+    size_t ws2_bytes = 0;
     // timers
     hipEvent_t t0[8];
     hipEvent_t t1[8];
@@ -67,7 +69,8 @@ struct sx_ctx {
     int opt_graph = 1;       // replay the CG iteration batch as a hipGraph
 };
 
-int sx_reserve(sx_ctx *ctx, size_t bytes); // ensure ctx->ws holds >= bytes
+int sx_reserve(sx_ctx *ctx, size_t bytes);  // ensure ctx->ws holds >= bytes
+int sx_reserve2(sx_ctx *ctx, size_t bytes); // ensure ctx->ws2 holds >= bytes
 
 struct sx_matrix {
     sx_ctx *ctx = nullptr;

@@ -129,47 +129,30 @@ SX_API int sx_argsort_desc_dev(sx_ctx *ctx, int64_t n, const double *key, int64_
     SX_REQUIRE(key && idx_out, "NULL argument");
     const int64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
     hipStream_t s = ctx->stream;
-    uint64_t *img[2] = {nullptr, nullptr};
-    int32_t *idx[2] = {nullptr, nullptr};
-    int64_t *hist = nullptr, *offs = nullptr;
-    int rc = SX_OK;
-    hipError_t e = hipSuccess;
-    if ((e = hipMalloc(reinterpret_cast<void **>(&img[0]), sizeof(uint64_t) * n)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&img[1]), sizeof(uint64_t) * n)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&idx[0]), sizeof(int32_t) * n)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&idx[1]), sizeof(int32_t) * n)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&hist), sizeof(int64_t) * 256 * nblocks)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&offs), sizeof(int64_t) * (256 * nblocks + 1))) != hipSuccess) {
-        sx_set_error("hipMalloc failed in sx_argsort_desc: %s", hipGetErrorString(e));
-        rc = SX_ERR_NOMEM;
+    // double buffers and histograms live in the context's second grow-only block (the scan helper works
+    // in the first one): no allocation and no host synchronisation per call once the block is large enough
+    const size_t n8 = (sizeof(uint64_t) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255);
+    const size_t n4 = (sizeof(int32_t) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255);
+    const size_t nh = (sizeof(int64_t) * (256 * static_cast<size_t>(nblocks) + 1) + 255) & ~static_cast<size_t>(255);
+    SX_TRY(sx_reserve2(ctx, 2 * n8 + 2 * n4 + 2 * nh));
+    char *base = static_cast<char *>(ctx->ws2);
+    uint64_t *img[2] = {reinterpret_cast<uint64_t *>(base), reinterpret_cast<uint64_t *>(base + n8)};
+    int32_t *idx[2] = {reinterpret_cast<int32_t *>(base + 2 * n8), reinterpret_cast<int32_t *>(base + 2 * n8 + n4)};
+    int64_t *hist = reinterpret_cast<int64_t *>(base + 2 * n8 + 2 * n4);
+    int64_t *offs = reinterpret_cast<int64_t *>(base + 2 * n8 + 2 * n4 + nh);
+
+    hipLaunchKernelGGL(k_sort_init, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, key, img[0], idx[0]);
+    int cur = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_sort_hist, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur], shift,
+                           nblocks, hist);
+        SX_TRY(sx_scan_exclusive(ctx, hist, 256 * nblocks, offs));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur],
+                           idx[cur], shift, nblocks, offs, img[cur ^ 1], idx[cur ^ 1]);
+        cur ^= 1;
     }
-    if (rc == SX_OK) {
-        hipLaunchKernelGGL(k_sort_init, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, key, img[0], idx[0]);
-        int cur = 0;
-        for (int pass = 0; pass < 8 && rc == SX_OK; ++pass) {
-            const int shift = 8 * pass;
-            hipLaunchKernelGGL(k_sort_hist, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur],
-                               shift, nblocks, hist);
-            rc = sx_scan_exclusive(ctx, hist, 256 * nblocks, offs);
-            if (rc != SX_OK) break;
-            hipLaunchKernelGGL(k_sort_scatter, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur],
-                               idx[cur], shift, nblocks, offs, img[cur ^ 1], idx[cur ^ 1]);
-            cur ^= 1;
-        }
-        if (rc == SX_OK) {
-            hipLaunchKernelGGL(k_sort_reverse, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, idx[cur], idx_out);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                sx_set_error("radix sort kernels failed");
-                rc = SX_ERR_HIP;
-            }
-        }
-    }
-    (void)hipStreamSynchronize(s);
-    for (int k = 0; k < 2; ++k) {
-        if (img[k]) (void)hipFree(img[k]);
-        if (idx[k]) (void)hipFree(idx[k]);
-    }
-    if (hist) (void)hipFree(hist);
-    if (offs) (void)hipFree(offs);
-    return rc;
+    hipLaunchKernelGGL(k_sort_reverse, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, idx[cur], idx_out);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
 }
