@@ -310,6 +310,23 @@ int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const
                          const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
                          double *x, double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
 
+/* Session: keeps the basis inverse of the last solve on the device so that the next solve of a
+ * column-generation sequence (network_methods/algorithms.py:105-139: same rows, more columns, warm basis
+ * = previous optimal basis) starts from it instead of re-installing the basis pivot by pivot.
+ * col_ids (HOST pointer, n entries) names the structural columns by identifiers that are stable from one
+ * solve to the next (e.g. the arc index in the full problem); the inverse is reused when the warm
+ * basis consists of exactly the variables the session's inverse belongs to, otherwise the call
+ * behaves like sx_simplex_solve_dev.  result->warm_start_used is 2 when the inverse was reused.
+ * One session serves one sequence; it must not be shared between contexts or threads. */
+typedef struct sx_simplex_session sx_simplex_session;
+int sx_simplex_session_create(sx_ctx *ctx, sx_simplex_session **out);
+int sx_simplex_session_destroy(sx_simplex_session *session);
+int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *A, const double *b,
+                                 const double *c, const double *l, const double *u, const uint8_t *row_is_lt,
+                                 const int8_t *vbasis_in, const int8_t *cbasis_in, const int64_t *col_ids,
+                                 int64_t max_iter, double feas_tol, double opt_tol, double *x, double *y,
+                                 int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
+
 #ifdef __cplusplus
 }
 #endif

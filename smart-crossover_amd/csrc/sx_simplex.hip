@@ -33,6 +33,7 @@
 #include "sx_segwalk.h"
 
 #include <cmath>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -121,16 +122,29 @@ __device__ __forceinline__ double score_of(int st, double rc, double lo, double 
 }
 
 // ------------------------------------------------------------------ pricing
+// one launch prices everything: workgroups [0, gP) walk the structural columns, [gP, gridDim) the logicals
 __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__restrict__ tiles, int64_t ntiles,
                                                      const int64_t *__restrict__ colptr,
                                                      const int32_t *__restrict__ rowidx,
-                                                     const double *__restrict__ val, double tol) {
+                                                     const double *__restrict__ val, double tol, int gP) {
     if (P.st->done) return;
     __shared__ sx_walk_lds<1, SPX_CHUNK> lds;
     const int bland = P.st->bland;
     double s = 0.0, rc = 0.0;
     long long j = -1;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (static_cast<int>(blockIdx.x) >= gP) { // logical columns e_i: rc = cost - y_i
+        const int gL = gridDim.x - gP;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x - gP) * SX_WG + threadIdx.x; i < P.m;
+             i += static_cast<int64_t>(gL) * SX_WG) {
+            const int64_t k = P.n + i;
+            const double r = P.cost[k] - P.y[i];
+            const double sc = score_of(P.status[k], r, P.lo[k], P.up[k], tol, bland);
+            if (sc > 0.0) better(s, j, rc, sc, k, r);
+        }
+        block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, blockIdx.x);
+        return;
+    }
+    for (int64_t t = blockIdx.x; t < ntiles; t += gP) {
         double acc[1];
         int64_t col;
         bool valid;
@@ -144,51 +158,53 @@ __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__res
     block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, blockIdx.x);
 }
 
-__global__ __launch_bounds__(SX_WG) void k_spx_price_logical(Spx P, int slot0, double tol) {
-    if (P.st->done) return;
-    const int bland = P.st->bland;
-    double s = 0.0, rc = 0.0;
-    long long j = -1;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < P.m;
-         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
-        const int64_t k = P.n + i;
-        const double r = P.cost[k] - P.y[i];
-        const double sc = score_of(P.status[k], r, P.lo[k], P.up[k], tol, bland);
-        if (sc > 0.0) better(s, j, rc, sc, k, r);
-    }
-    block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, slot0 + blockIdx.x);
-}
-
-__global__ __launch_bounds__(SX_WG) void k_spx_select(Spx P, int nslots) {
-    SpxState *st = P.st;
-    if (st->done) return;
-    double s = 0.0, rc = 0.0;
-    long long j = -1;
-    for (int k = threadIdx.x; k < nslots; k += SX_WG) better(s, j, rc, P.p_score[k], P.p_idx[k], P.p_rc[k]);
-    block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, 0); // slot 0 is free to reuse: every slot was read above
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s = P.p_score[0];
-        j = P.p_idx[0];
-        rc = P.p_rc[0];
-        if (j < 0 || s <= 0.0) {
-            st->done = 1;
-            st->q = -1;
-        } else {
-            st->q = static_cast<int>(j);
-            st->rc_q = rc;
-            const int stq = P.status[j];
-            st->dir = (stq == ST_LOWER) ? 1 : (stq == ST_UPPER) ? -1 : (rc < 0 ? 1 : -1);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ ftran: d = Binv * a_q
+// In the pivot loop (q_override < 0) every workgroup first repeats the selection of the entering column
+// from the pricing partials -- a deterministic reduction, so all arrive at the same q without another
+// launch -- and workgroup 0 records it in the state.
 __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__restrict__ colptr,
                                                      const int32_t *__restrict__ rowidx,
-                                                     const double *__restrict__ val, int q_override) {
-    if (P.st->done && q_override < 0) return;
-    const int64_t q = q_override >= 0 ? q_override : P.st->q;
+                                                     const double *__restrict__ val, int q_override, int nslots) {
+    __shared__ double sh_s[SX_WG / 64], sh_rc[SX_WG / 64];
+    __shared__ long long sh_j[SX_WG / 64];
+    int64_t q = q_override;
+    if (q_override < 0) {
+        SpxState *st = P.st;
+        if (st->done) return;
+        double s = 0.0, rc = 0.0;
+        long long j = -1;
+        for (int k = threadIdx.x; k < nslots; k += SX_WG) better(s, j, rc, P.p_score[k], P.p_idx[k], P.p_rc[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double s2 = __shfl_down(s, o, 64), r2 = __shfl_down(rc, o, 64);
+            const long long j2 = __shfl_down(j, o, 64);
+            better(s, j, rc, s2, j2, r2);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sh_s[threadIdx.x >> 6] = s;
+            sh_j[threadIdx.x >> 6] = j;
+            sh_rc[threadIdx.x >> 6] = rc;
+        }
+        __syncthreads();
+        s = sh_s[0];
+        j = sh_j[0];
+        rc = sh_rc[0];
+        for (int w = 1; w < SX_WG / 64; ++w) better(s, j, rc, sh_s[w], sh_j[w], sh_rc[w]);
+        const bool none = j < 0 || s <= 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (none) {
+                st->done = 1;
+                st->q = -1;
+            } else {
+                st->q = static_cast<int>(j);
+                st->rc_q = rc;
+                const int stq = P.status[j];
+                st->dir = (stq == ST_LOWER) ? 1 : (stq == ST_UPPER) ? -1 : (rc < 0 ? 1 : -1);
+            }
+        }
+        if (none) return;
+        q = j;
+    }
     const int64_t m = P.m;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
          i += static_cast<int64_t>(gridDim.x) * SX_WG) {
@@ -305,23 +321,29 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P) {
         P.rho[k] = P.Binv[r + k * m];
 }
 
-// x_B -= t*dir*d ;  y += (rc_q / alpha) * rho
-__global__ __launch_bounds__(SX_WG) void k_spx_update_vec(Spx P) {
+// pivot loop: rho as above and, in the same launch, x_B -= t*dir*d ;  y += (rc_q / alpha) * rho
+// (element i needs only its own rho[i])
+__global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P) {
     const SpxState *st = P.st;
     if (st->done) return;
     const double step = st->t * st->dir;
     const bool pivot = !st->flip;
     const double mult = pivot ? st->rc_q / st->alpha : 0.0;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < P.m;
+    const int64_t m = P.m, r = st->r;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
          i += static_cast<int64_t>(gridDim.x) * SX_WG) {
         const int k = P.head[i];
         P.x[k] = P.x[k] - step * P.d[i];
-        if (pivot) P.y[i] = P.y[i] + mult * P.rho[i];
+        if (pivot) {
+            const double rho_i = P.Binv[r + i * m];
+            P.rho[i] = rho_i;
+            P.y[i] = P.y[i] + mult * rho_i;
+        }
     }
 }
 
 // basis bookkeeping of one pivot (single lane)
-__global__ void k_spx_commit(Spx P) {
+__device__ __forceinline__ void spx_commit(const Spx &P) {
     SpxState *st = P.st;
     if (st->done) return;
     const int q = st->q;
@@ -353,17 +375,22 @@ __global__ void k_spx_commit(Spx P) {
     st->iters += 1;
 }
 
+// The bookkeeping stays a launch of its own: folding it into the last workgroup of k_spx_update_binv
+// (ticket counter) was measured 3x slower overall -- thousands of atomics on one address cost far more
+// than the ~4 us launch they save.
+__global__ void k_spx_commit(Spx P) { spx_commit(P); }
+
 // Binv -= dhat * rho^T with dhat_i = d_i/alpha (i != r), dhat_r = (alpha - 1)/alpha
 __global__ __launch_bounds__(SX_WG) void k_spx_update_binv(Spx P) {
     const SpxState *st = P.st;
     if (st->done || st->flip) return;
     const int64_t m = P.m, r = st->r;
-    const double inv = 1.0 / st->alpha;
+    const double alpha = st->alpha, inv = 1.0 / alpha;
     const int64_t total = m * m;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; e < total;
          e += static_cast<int64_t>(gridDim.x) * SX_WG) {
         const int64_t k = e / m, i = e - k * m;
-        const double dh = (i == r) ? (st->alpha - 1.0) * inv : P.d[i] * inv;
+        const double dh = (i == r) ? (alpha - 1.0) * inv : P.d[i] * inv;
         P.Binv[e] = fma(-dh, P.rho[k], P.Binv[e]);
     }
 }
@@ -505,13 +532,26 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rhs(Spx P, const int64_t *__restr
 }
 
 // x_B = Binv rhs  (row i of Binv dotted with rhs; column-major -> lanes walk i, loop over k)
-__global__ __launch_bounds__(SX_WG) void k_spx_xb(Spx P) {
+// A workgroup of 16 waves owns 64 rows; wave w sums the columns k = w, w + 16, ... and the 16 partial sums
+// are added in wave order (fixed order -> the same x_B on every run).
+__global__ __launch_bounds__(1024) void k_spx_xb(Spx P) {
+    __shared__ double part[16][64];
     const int64_t m = P.m;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
-         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * 64; i0 < m; i0 += static_cast<int64_t>(gridDim.x) * 64) {
+        const int64_t i = i0 + lane;
         double acc = 0.0;
-        for (int64_t k = 0; k < m; ++k) acc = fma(P.Binv[i + k * m], P.rhs[k], acc);
-        P.x[P.head[i]] = acc;
+        if (i < m)
+            for (int64_t k = wave; k < m; k += 16) acc = fma(P.Binv[i + k * m], P.rhs[k], acc);
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && i < m) {
+            double tot = part[0][lane];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) tot += part[w][lane];
+            P.x[P.head[i]] = tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -668,14 +708,72 @@ struct DevBufs {
     }
 };
 
+// install a basis whose inverse is already in P.Binv: every logical non-basic first, then the head
+__global__ __launch_bounds__(SX_WG) void k_spx_logicals_out(Spx P) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < P.m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const int64_t k = P.n + i;
+        P.status[k] = ST_LOWER;
+        P.x[k] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(SX_WG) void k_spx_install_head(Spx P, const int32_t *__restrict__ head_new) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < P.m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const int32_t k = head_new[i];
+        P.head[i] = k;
+        P.status[k] = ST_BASIC;
+    }
+}
+
 } // namespace
+
+struct sx_simplex_session {
+    sx_ctx *ctx = nullptr;
+    int64_t m = 0;
+    double *Binv = nullptr;        // device, m x m column-major, owned
+    std::vector<int64_t> head_ids; // per basis position: structural id (>= 0) or -(row + 1) for a logical
+    bool valid = false;
+};
+
+SX_API int sx_simplex_session_create(sx_ctx *ctx, sx_simplex_session **out) {
+    SX_REQUIRE(ctx != nullptr && out != nullptr, "ctx or out is NULL");
+    sx_simplex_session *s = new (std::nothrow) sx_simplex_session();
+    if (!s) {
+        sx_set_error("out of host memory");
+        return SX_ERR_NOMEM;
+    }
+    s->ctx = ctx;
+    *out = s;
+    return SX_OK;
+}
+
+SX_API int sx_simplex_session_destroy(sx_simplex_session *session) {
+    if (!session) return SX_OK;
+    sx_device_guard guard(session->ctx->device);
+    if (session->Binv) (void)hipFree(session->Binv);
+    delete session;
+    return SX_OK;
+}
 
 SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
                                 const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
                                 const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
                                 double *x_out, double *y_out, int8_t *vbasis_out, int8_t *cbasis_out,
                                 sx_simplex_result *result) {
+    return sx_simplex_solve_session_dev(ctx, nullptr, A, b, c, l, u, row_is_lt, vbasis_in, cbasis_in, nullptr, max_iter,
+                                        feas_tol, opt_tol, x_out, y_out, vbasis_out, cbasis_out, result);
+}
+
+SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *A, const double *b,
+                                        const double *c, const double *l, const double *u, const uint8_t *row_is_lt,
+                                        const int8_t *vbasis_in, const int8_t *cbasis_in, const int64_t *col_ids,
+                                        int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
+                                        double *y_out, int8_t *vbasis_out, int8_t *cbasis_out,
+                                        sx_simplex_result *result) {
     SX_ENTER(ctx);
+    SX_REQUIRE(session == nullptr || session->ctx == ctx, "the session belongs to another context");
     SX_REQUIRE(A && b && c && l && u && row_is_lt && result, "NULL argument");
     SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the simplex needs both layouts of A");
     SX_REQUIRE((vbasis_in == nullptr) == (cbasis_in == nullptr), "vbasis_in and cbasis_in go together");
@@ -705,7 +803,19 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     SX_TRY(mem.get(static_cast<size_t>(m), &P.d));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.rho));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.rhs));
-    SX_TRY(mem.get(static_cast<size_t>(m) * static_cast<size_t>(m), &P.Binv));
+    if (session) { // the inverse outlives the call
+        if (session->m != m || session->Binv == nullptr) {
+            if (session->Binv) SX_HIP(hipFree(session->Binv));
+            session->Binv = nullptr;
+            session->valid = false;
+            session->m = m;
+            SX_HIP(hipMalloc(reinterpret_cast<void **>(&session->Binv),
+                             sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(m) + 1)));
+        }
+        P.Binv = session->Binv;
+    } else {
+        SX_TRY(mem.get(static_cast<size_t>(m) * static_cast<size_t>(m), &P.Binv));
+    }
     SX_TRY(mem.get(1, &P.st));
     const int gP = static_cast<int>(A->n_csc_tiles < SPX_GRID ? (A->n_csc_tiles > 0 ? A->n_csc_tiles : 1) : SPX_GRID);
     const int gL = static_cast<int>(grid1d(m, 64));
@@ -723,7 +833,7 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     auto refresh = [&](bool with_y) {
         hipLaunchKernelGGL(k_spx_rhs, dim3(gR), dim3(SX_WG), 0, s, P, A->csr_tiles, A->n_csr_tiles, A->csr_ptr,
                            A->csr_idx, A->csr_val);
-        hipLaunchKernelGGL(k_spx_xb, dim3(gM), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_xb, dim3(grid1d(m * 4, 2048)), dim3(1024), 0, s, P); // one workgroup per 64 rows
         if (with_y) hipLaunchKernelGGL(k_spx_btran, dim3(grid1d(m * 64)), dim3(SX_WG), 0, s, P);
     };
     double host_meas[3] = {0, 0, 0};
@@ -739,17 +849,66 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     };
 
     // ---- starting basis
-    cold_start(1);
-    bool warm = false;
+    bool warm = false, reused = false;
+    std::vector<int8_t> vb;
     if (vbasis_in) {
-        std::vector<int8_t> vb(static_cast<size_t>(n));
+        vb.resize(static_cast<size_t>(n));
         SX_HIP(hipMemcpyAsync(vb.data(), vbasis_in, static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
         SX_HIP(hipStreamSynchronize(s));
+    }
+    if (session && session->valid && vbasis_in && col_ids && static_cast<int64_t>(session->head_ids.size()) == m) {
+        // the session's inverse serves when the warm basis names exactly the variables it belongs to
+        std::vector<int8_t> cb(static_cast<size_t>(m));
+        SX_HIP(hipMemcpyAsync(cb.data(), cbasis_in, static_cast<size_t>(m), hipMemcpyDeviceToHost, s));
+        SX_HIP(hipStreamSynchronize(s));
+        std::unordered_map<int64_t, int32_t> basic_of_id;
+        int64_t n_basic = 0;
+        for (int64_t j = 0; j < n; ++j)
+            if (vb[static_cast<size_t>(j)] == ST_BASIC) {
+                basic_of_id.emplace(col_ids[j], static_cast<int32_t>(j));
+                ++n_basic;
+            }
+        for (int64_t i = 0; i < m; ++i) n_basic += (cb[static_cast<size_t>(i)] == 0) ? 1 : 0;
+        std::vector<int32_t> head_new(static_cast<size_t>(m));
+        bool ok = n_basic == m;
+        for (int64_t i = 0; ok && i < m; ++i) {
+            const int64_t id = session->head_ids[static_cast<size_t>(i)];
+            if (id >= 0) {
+                auto it = basic_of_id.find(id);
+                if (it == basic_of_id.end()) ok = false;
+                else {
+                    head_new[static_cast<size_t>(i)] = it->second;
+                    basic_of_id.erase(it); // every basic column serves one position
+                }
+            } else {
+                const int64_t r = -(id + 1);
+                if (r >= m || cb[static_cast<size_t>(r)] != 0) ok = false;
+                else head_new[static_cast<size_t>(i)] = static_cast<int32_t>(n + r);
+            }
+        }
+        if (ok && basic_of_id.empty()) {
+            int32_t *head_dev = nullptr;
+            SX_TRY(mem.get(static_cast<size_t>(m), &head_dev));
+            SX_HIP(hipMemcpyAsync(head_dev, head_new.data(), sizeof(int32_t) * static_cast<size_t>(m),
+                                  hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_spx_init, dim3(gN), dim3(SX_WG), 0, s, P, l, u, c, 1);
+            hipLaunchKernelGGL(k_spx_apply_vbasis, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in);
+            hipLaunchKernelGGL(k_spx_logicals_out, dim3(gM), dim3(SX_WG), 0, s, P);
+            hipLaunchKernelGGL(k_spx_install_head, dim3(gM), dim3(SX_WG), 0, s, P, head_dev);
+            hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
+            refresh(true);
+            SX_TRY(measure()); // synchronises: head_new may go out of scope afterwards
+            reused = warm = host_meas[0] <= feas_tol * 10;
+        }
+    }
+    if (session) session->valid = false; // until this solve has left a basis behind
+    if (!reused) cold_start(1);
+    if (vbasis_in && !reused) {
         hipLaunchKernelGGL(k_spx_apply_vbasis, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in);
         for (int64_t j = 0; j < n; ++j) {
             if (vb[static_cast<size_t>(j)] != ST_BASIC) continue;
             hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val,
-                               static_cast<int>(j));
+                               static_cast<int>(j), 0);
             hipLaunchKernelGGL(k_spx_crash_pick, dim3(1), dim3(1024), 0, s, P, static_cast<int>(j), cbasis_in);
             hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P);
             hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
@@ -766,18 +925,15 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     SpxState host;
     memset(&host, 0, sizeof(host));
     auto enqueue_pivot = [&]() {
-        hipLaunchKernelGGL(k_spx_price, dim3(gP), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
-                           A->csc_idx, A->csc_val, opt_tol);
-        hipLaunchKernelGGL(k_spx_price_logical, dim3(gL), dim3(SX_WG), 0, s, P, gP, opt_tol);
-        hipLaunchKernelGGL(k_spx_select, dim3(1), dim3(SX_WG), 0, s, P, gP + gL);
-        hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1);
+        hipLaunchKernelGGL(k_spx_price, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
+                           A->csc_idx, A->csc_val, opt_tol, gP);
+        hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1, gP + gL);
         hipLaunchKernelGGL(k_spx_ratio, dim3(1), dim3(1024), 0, s, P);
-        hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P);
-        hipLaunchKernelGGL(k_spx_update_vec, dim3(gM), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P);
         hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
         hipLaunchKernelGGL(k_spx_commit, dim3(1), dim3(1), 0, s, P);
     };
-    // a batch of 32 pivots = 288 small launches with fixed arguments: captured once into a hipGraph
+    // a batch of 32 pivots = 192 small launches with fixed arguments: captured once into a hipGraph
     // and replayed (pivots are launch-bound for small m); direct launches are the fallback
     const int batch = 32;
     hipGraph_t graph = nullptr;
@@ -858,6 +1014,16 @@ SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b
     result->phase1_iters = phase1_iters;
     result->obj = host_meas[2];
     result->max_violation = host_meas[0];
-    result->warm_start_used = warm ? 1 : 0;
+    result->warm_start_used = reused ? 2 : (warm ? 1 : 0);
+    if (session) { // remember which variables the inverse left in P.Binv belongs to
+        std::vector<int32_t> head_host(static_cast<size_t>(m));
+        SX_HIP(hipMemcpy(head_host.data(), P.head, sizeof(int32_t) * static_cast<size_t>(m), hipMemcpyDeviceToHost));
+        session->head_ids.resize(static_cast<size_t>(m));
+        for (int64_t i = 0; i < m; ++i) {
+            const int32_t k = head_host[static_cast<size_t>(i)];
+            session->head_ids[static_cast<size_t>(i)] = (k < n) ? (col_ids ? col_ids[k] : 0) : -(static_cast<int64_t>(k - n) + 1);
+        }
+        session->valid = col_ids != nullptr && status != 4;
+    }
     return SX_OK;
 }

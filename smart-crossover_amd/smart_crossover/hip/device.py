@@ -228,13 +228,29 @@ class Context:
         return res
 
     def simplex(self, A, b, c, l, u, row_is_lt, vbasis=None, cbasis=None, max_iter=0, feas_tol=1e-7, opt_tol=1e-7,
-                x=None, y=None, vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
-        """K16 (blocking): bounded primal simplex on the device; device pointers in and out."""
+                x=None, y=None, vbasis_out=None, cbasis_out=None, session: Optional["SimplexSession"] = None,
+                col_ids: Optional[np.ndarray] = None) -> "_l.SimplexResult":
+        """K16 (blocking): bounded primal simplex on the device; device pointers in and out.  With a
+        ``session`` and stable column identifiers ``col_ids`` (host int64) the basis inverse of the
+        previous solve is reused when the warm basis is that solve's final basis."""
         res = _l.SimplexResult()
-        _l.check(self._lib.sx_simplex_solve_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt),
-                                                _ptr(vbasis), _ptr(cbasis), int(max_iter), float(feas_tol), float(opt_tol),
-                                                _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+        if session is None:
+            _l.check(self._lib.sx_simplex_solve_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u),
+                                                    _ptr(row_is_lt), _ptr(vbasis), _ptr(cbasis), int(max_iter),
+                                                    float(feas_tol), float(opt_tol), _ptr(x), _ptr(y), _ptr(vbasis_out),
+                                                    _ptr(cbasis_out), C.byref(res)))
+            return res
+        ids = None if col_ids is None else np.ascontiguousarray(col_ids, dtype=np.int64)
+        if ids is not None and ids.size != A.shape[1]:
+            raise ValueError("col_ids must name every structural column")
+        _l.check(self._lib.sx_simplex_solve_session_dev(
+            self.handle, session.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt), _ptr(vbasis),
+            _ptr(cbasis), None if ids is None else ids.ctypes.data, int(max_iter), float(feas_tol), float(opt_tol),
+            _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
+
+    def simplex_session(self) -> "SimplexSession":
+        return SimplexSession(self)
 
     def x_real(self, n, x, l, u, out, apply_floor: bool = True) -> None:
         _l.check(self._lib.sx_x_real_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), int(bool(apply_floor)),
@@ -345,6 +361,28 @@ class DeviceMatrix:
     def free(self) -> None:
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.sx_matrix_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SimplexSession:
+    """Keeps the device simplex's basis inverse between the solves of one column-generation sequence
+    (sx_simplex_session_*)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _l.check(ctx._lib.sx_simplex_session_create(ctx.handle, C.byref(h)))
+        self.handle = h
+
+    def free(self) -> None:
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.sx_simplex_session_destroy(self.handle)
         self.handle = None
 
     def __del__(self):  # pragma: no cover

@@ -104,6 +104,10 @@ PROTOTYPES = {
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
     "sx_simplex_solve_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                     C.POINTER(SimplexResult)]),
+    "sx_simplex_session_create": (_int, [_vp, C.POINTER(_vp)]),
+    "sx_simplex_session_destroy": (_int, [_vp]),
+    "sx_simplex_solve_session_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp,
+                                            _vp, _vp, _vp, C.POINTER(SimplexResult)]),
     "sx_projector_norm": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
 }
 

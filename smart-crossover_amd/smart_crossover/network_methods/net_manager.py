@@ -89,6 +89,20 @@ class _ResidentMatrix:
 
 
 # ====================================================================================== MCF
+class _SessionHolder:
+    """Where a device-resident backend may keep state between the sub-problem solves of one manager
+    (the HIP simplex keeps its basis inverse here); other backends ignore it."""
+    session = None
+
+
+def _tag_sub_problem(sub: MinCostFlow, col_ids: np.ndarray, holder: _SessionHolder) -> None:
+    """Stable identifiers of the sub-problem's columns (their index in the full problem) and the state
+    holder, as plain attributes the reference's dataclass does not have; only backends that look for
+    them (solver_caller/hip.py) are affected."""
+    sub.col_ids = np.asarray(col_ids, dtype=_I64)
+    sub.hip_session = holder
+
+
 class MCFManagerStd:
     """min-cost-flow manager (reference net_manager.py:116-319)."""
 
@@ -102,6 +116,7 @@ class MCFManagerStd:
         self.artificial_vars = np.array([])
         self.c_rescaling_factor = None
         self._resident = _ResidentMatrix()
+        self._spx_holder = _SessionHolder()
 
     def _dev_matrix(self):
         self.mcf.A = _canonical(self.mcf.A)
@@ -167,6 +182,7 @@ class MCFManagerStd:
                       b_sub)
         self.mcf_sub = MinCostFlow(A=sub.to_scipy(), b=b_sub.download(), c=self.mcf.c[non_fix], u=self.mcf.u[non_fix])
         sub.free()
+        _tag_sub_problem(self.mcf_sub, non_fix, self._spx_holder)
 
     def solve_subproblem(self, solver: str, solver_settings: SolverSettings) -> Output:
         method = "network_simplex" if solver == "CPL" else "default"
@@ -253,6 +269,7 @@ class OTManager:
         self.mask_sub_ot = np.zeros(self.n, dtype=bool)
         self.artificial_vars = np.array([])
         self._resident = _ResidentMatrix()
+        self._spx_holder = _SessionHolder()
 
     def get_mcf(self) -> None:
         self.mcf = self.ot.to_MCF()
@@ -320,6 +337,7 @@ class OTManager:
         M = np.asarray(self.ot.M.toarray() if sp.issparse(self.ot.M) else self.ot.M)
         out = MinCostFlow(A=sub.to_scipy(), b=self.mcf.b, c=M.flatten()[mask], u=self.mcf.u[mask])
         sub.free()
+        _tag_sub_problem(out, cols, self._spx_holder)
         return out
 
     def solve_subproblem(self, solver: str, solver_settings: SolverSettings) -> Output:

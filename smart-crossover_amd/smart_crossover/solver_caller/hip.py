@@ -47,10 +47,15 @@ class HipCaller(SolverCaller):
     def read_genlp(self, genlp: GeneralLP) -> None:
         self._load(genlp.A, genlp.b, genlp.c, genlp.l, genlp.u, np.asarray(genlp.sense) == "<")
         self._resident = getattr(genlp, "_sx_resident", None)
+        self._col_ids = self._session_holder = None
 
     def read_stdlp(self, stdlp: StandardLP) -> None:
         self._load(stdlp.A, stdlp.b, stdlp.c, stdlp.l, stdlp.u, np.zeros(np.asarray(stdlp.b).size, dtype=bool))
         self._resident = None
+        # column-generation sequences (network managers) tag their sub-problems: stable column identifiers
+        # and a holder in which the device simplex keeps its basis inverse from one round to the next
+        self._col_ids = getattr(stdlp, "col_ids", None)
+        self._session_holder = getattr(stdlp, "hip_session", None)
 
     def get_A(self) -> sp.csr_matrix:
         return self._A
@@ -92,9 +97,16 @@ class HipCaller(SolverCaller):
         if self._warm is not None and self._warm.vbasis.size == n and self._warm.cbasis.size == m:
             vb_in = ctx.to_device(np.clip(self._warm.vbasis, -3, 0).astype(np.int8))
             cb_in = ctx.to_device(np.clip(self._warm.cbasis, -1, 0).astype(np.int8))
+        session, col_ids = None, getattr(self, "_col_ids", None)
+        holder = getattr(self, "_session_holder", None)
+        if holder is not None and col_ids is not None:
+            if getattr(holder, "session", None) is None:
+                holder.session = ctx.simplex_session()
+            session = holder.session
         t0 = time.perf_counter()
         self._res = ctx.simplex(dA, put(self._b), put(self._c), put(self._l), put(self._u), ctx.to_device(self._row_lt),
-                                vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
+                                vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb,
+                                session=session, col_ids=col_ids)
         self._runtime = time.perf_counter() - t0
         self._x, self._y = d_x.download(), d_y.download()
         self._vb, self._cb = d_vb.download().astype(int), d_cb.download().astype(int)

@@ -160,3 +160,64 @@ def test_perturbation_crossover_with_split_backend():
     assert out.status == "OPTIMAL"
     if "A primal optimal BFS is found" not in buf.getvalue():
         check_vertex(lp, out, ref.obj_val)
+
+
+def test_session_reuses_the_inverse_across_column_generation_rounds():
+    """A second solve whose warm basis is the first solve's final basis (same rows, more columns, columns
+    named by stable ids) starts from the kept inverse (warm_start_used == 2), pivots on, and ends at
+    the optimum of the larger problem; a basis the session does not know falls back to the crash."""
+    from smart_crossover.hip import Context
+    ctx = Context(0)
+    mi = workloads.mcf(60, 500, seed=17)
+    V, E = mi.A.shape
+    # big-M style start: artificial columns +-e_i make any subset of arcs feasible
+    sign = np.where(mi.b >= 0, 1.0, -1.0)
+    art = sp.diags(sign).tocsr()
+    A_full = sp.hstack([mi.A, art]).tocsr()
+    c_full = np.concatenate([mi.c, np.full(V, 1e6)])
+    u_full = np.concatenate([mi.u, np.full(V, np.inf)])
+    ids_all = np.arange(E + V, dtype=np.int64)
+
+    def solve(cols, session, warm):
+        A = A_full[:, cols]
+        dA = ctx.matrix(A)
+        n = cols.size
+        put = lambda v: ctx.to_device(np.ascontiguousarray(v, dtype=np.float64))   # noqa: E731
+        x, y = ctx.empty(n, np.float64), ctx.empty(V, np.float64)
+        vb, cb = ctx.empty(n, np.int8), ctx.empty(V, np.int8)
+        vin = cin = None
+        if warm is not None:
+            vin, cin = ctx.to_device(warm[0].astype(np.int8)), ctx.to_device(warm[1].astype(np.int8))
+        res = ctx.simplex(dA, put(mi.b), put(c_full[cols]), put(np.zeros(n)), put(u_full[cols]),
+                          ctx.to_device(np.zeros(V, dtype=np.uint8)), vin, cin, 0, 1e-7, 1e-7, x, y, vb, cb,
+                          session=session, col_ids=ids_all[cols])
+        out = (res, x.download(), vb.download().astype(int), cb.download().astype(int))
+        dA.free()
+        return out
+
+    sess = ctx.simplex_session()
+    first = np.concatenate([np.arange(0, E, 3), np.arange(E, E + V)])           # a third of the arcs + artificials
+    r1, x1, vb1, cb1 = solve(first, sess, None)
+    assert r1.status == 0 and r1.warm_start_used == 0
+    second = np.arange(E + V)                                                    # every arc
+    warm_vb = np.full(second.size, -1)
+    warm_vb[first] = vb1                                                         # new columns non-basic at lower
+    r2, x2, vb2, cb2 = solve(second, sess, (warm_vb, cb1))
+    assert r2.status == 0 and r2.warm_start_used == 2
+    # same optimum as a cold solve without a session, and as HiGHS
+    r3, x3, _, _ = solve(second, None, None)
+    assert r3.status == 0 and r2.obj == pytest.approx(r3.obj, rel=1e-9)
+    from scipy.optimize import linprog
+    ref = linprog(c_full, A_eq=A_full, b_eq=mi.b, bounds=list(zip(np.zeros(E + V), [None if np.isinf(v) else v for v in u_full])),
+                  method="highs")
+    assert ref.status == 0
+    want = ref.fun
+    assert r2.obj == pytest.approx(want, rel=1e-9)
+    assert np.allclose(A_full @ x2, mi.b, atol=1e-6)
+    # a warm basis that is not the session's: ordinary crash (1) or cold start (0), still optimal
+    other_vb = np.full(second.size, -1)
+    other_vb[E:] = 0
+    r4, _, _, _ = solve(second, sess, (other_vb, np.full(V, -1)))
+    assert r4.status == 0 and r4.warm_start_used in (0, 1) and r4.obj == pytest.approx(want, rel=1e-9)
+    sess.free()
+    ctx.close()
