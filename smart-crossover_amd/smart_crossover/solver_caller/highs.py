@@ -198,8 +198,15 @@ class HgsCaller(SolverCaller):
         self._apply_settings()
         self.h.setOptionValue("solver", solver)
         self.h.setOptionValue("run_crossover", crossover)
+        if solver == "ipm" and crossover == "off":
+            # An interior point without crossover cannot be postsolved reliably by this HiGHS: when the
+            # run ends "Unknown" (IPX optimal, tiny residual corrections) the returned column values belong
+            # to the presolved model (c^T x != reported objective).  The interior point is the *input* of
+            # the perturbation crossover, so it is computed on the unpresolved model.
+            self.h.setOptionValue("presolve", "off")
         if strategy is not None:
             self.h.setOptionValue("simplex_strategy", strategy)
+        self._ipm_certificate = None
         t0 = time.perf_counter()
         self.h.run()
         self._runtime = time.perf_counter() - t0
@@ -253,7 +260,50 @@ class HgsCaller(SolverCaller):
             return "INFEASIBLE"
         if st == ms.kUnbounded:
             return "UNBOUNDED"
+        if st == ms.kUnknown and getattr(self, "_crossover_off", False):
+            # An interior-point run without crossover that IPX itself reports optimal comes back as
+            # "Unknown" when the postsolved point needs tiny residual corrections ("basis is not valid;
+            # solution is valid").  Gurobi reports such a barrier-only run as OPTIMAL; so does this.
+            if self._bar_iters > 0 and self._interior_point_is_optimal():
+                return "OPTIMAL"
         return "UNKNOWN"
+
+    def _interior_point_is_optimal(self, tol: float = 1e-6) -> bool:
+        """KKT certificate of an interior (x, y) that carries no basis: primal residuals, sign of the
+        reduced costs on infinite bounds, and the duality gap against the bound-aware dual objective.
+        (HiGHS' own infeasibility counts are meaningless here: they assume non-basic variables sit on
+        a bound.)"""
+        cached = getattr(self, "_ipm_certificate", None)
+        if cached is not None:
+            return cached
+        sol = self.h.getSolution()
+        ok = False
+        if sol.value_valid and sol.dual_valid:
+            inf = self.hc.kHighsInf
+            x, y = np.array(sol.col_value), np.array(sol.row_dual)
+            A = sp.csr_matrix(self._A)
+            c = np.asarray(self._c, dtype=float)
+            l, u = np.asarray(self._l, dtype=float), np.asarray(self._u, dtype=float)
+            lo, up = self._row_lower, self._row_upper
+            ax = A @ x
+            scale_b = 1.0 + max(float(np.max(np.abs(lo[np.abs(lo) < inf]), initial=0.0)),
+                                float(np.max(np.abs(up[np.abs(up) < inf]), initial=0.0)))
+            p_res = max(float(np.max(np.maximum(lo - ax, 0.0), initial=0.0)), float(np.max(np.maximum(ax - up, 0.0), initial=0.0)),
+                        float(np.max(np.maximum(l - x, 0.0), initial=0.0)), float(np.max(np.maximum(x - u, 0.0), initial=0.0)))
+            rc = c - A.T @ y
+            scale_c = 1.0 + float(np.max(np.abs(c), initial=0.0))
+            d_res = max(float(np.max(np.where(l <= -inf, np.maximum(rc, 0.0), 0.0), initial=0.0)),
+                        float(np.max(np.where(u >= inf, np.maximum(-rc, 0.0), 0.0), initial=0.0)),
+                        float(np.max(np.where(lo <= -inf, np.maximum(y, 0.0), 0.0), initial=0.0)),
+                        float(np.max(np.where(up >= inf, np.maximum(-y, 0.0), 0.0), initial=0.0)))
+            with np.errstate(invalid="ignore"):
+                dual_obj = (float(np.sum(np.where(y > 0, np.where(lo > -inf, lo, 0.0) * y, np.where(up < inf, up, 0.0) * y)))
+                            + float(np.sum(np.where(rc > 0, np.where(l > -inf, l, 0.0) * rc, np.where(u < inf, u, 0.0) * rc))))
+            primal_obj = float(c @ x)
+            gap = abs(primal_obj - dual_obj) / (1.0 + abs(primal_obj))
+            ok = p_res <= 1e-4 * scale_b and d_res <= 1e-4 * scale_c and gap <= tol
+        self._ipm_certificate = ok
+        return ok
 
     def return_x(self) -> np.ndarray:
         assert self.return_status() == "OPTIMAL", "The model is not solved to optimal!"

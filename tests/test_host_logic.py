@@ -381,3 +381,22 @@ def test_gurobi_style_summary_lines_in_log(tmp_path):
     spx = re.findall(r"Solved in (\d+) iterations and (\d+\.\d+) seconds", text)
     assert len(bar) == 1 and int(bar[0][0]) == out_b.bar_iter_count
     assert len(spx) == 2 and int(spx[1][0]) == out_s.iter_count
+
+
+def test_barrier_without_crossover_returns_a_consistent_interior_point():
+    """The input of the perturbation crossover: HiGHS ends such runs "Unknown" on larger models although
+    IPX converged; the stand-in certifies the interior point itself (KKT residuals + duality gap) and
+    solves the unpresolved model, because the presolved run hands back inconsistent column values."""
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.solver_caller.solving import solve_lp
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.sparse_lp(300, 1500, 5, seed=22, frac_upper=0.3)
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    out = solve_lp(lp, "HGS", method="barrier", settings=SolverSettings(crossover="off", log_console=0))
+    assert out.status == "OPTIMAL" and out.basis is None and out.bar_iter_count > 0
+    assert float(lp.c @ out.x) == pytest.approx(out.obj_val, rel=1e-9)
+    ref = solve_lp(lp, "HGS", method="default", settings=SolverSettings(log_console=0))
+    assert out.obj_val == pytest.approx(ref.obj_val, rel=1e-6)
+    assert np.all(lp.A @ out.x <= lp.b + 1e-5) and np.all(out.x >= lp.l - 1e-7) and np.all(out.x <= lp.u + 1e-7)
+    # an interior point: the variables that vanish at the vertex are tiny but strictly inside their bounds
+    assert np.count_nonzero((out.x > lp.l) & (out.x < lp.l + 1e-6)) > 100
