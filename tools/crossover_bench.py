@@ -142,7 +142,8 @@ def run_lp(solver, limit, m=2000, n=10000, k=5):
     of the crossover and is reported separately; everything after it is the crossover."""
     from smart_crossover.formats import GeneralLP
     from smart_crossover.lp_methods import algorithms as alg
-    inst = workloads.sparse_lp(m, n, k, seed=3, stratified=True, frac_upper=0.3)
+    inst = workloads.config2() if m == 20_000 else workloads.sparse_lp(m, n, k, seed=3, stratified=True, frac_upper=0.3)
+    m, n = inst.A.shape
     lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
     calls = []
     orig = alg.solve_lp
@@ -195,6 +196,8 @@ def main():
                 rec = run_mcf(args.solver, args.time_limit)
             elif case == "lp":
                 rec = run_lp(args.solver, args.time_limit)
+            elif case == "lp_c2":
+                rec = run_lp(args.solver, args.time_limit, m=20_000, n=100_000, k=20)
             else:
                 raise SystemExit(f"unknown case {case}")
             rec["process_state"] = "cold (first device call of the process)" if first else "warm"
