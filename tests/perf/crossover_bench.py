@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end network crossover at BASELINE sizes through the kept Python API (host memory in, basis out).
 
-    python tools/crossover_bench.py [--case c3_tnet|c3_cnet|c4_cnet|all] [--solver HGS] [--time-limit 600]
+    python tests/perf/crossover_bench.py [--case c3_tnet|c3_cnet|c4_cnet|all] [--solver HGS] [--time-limit 600]
 
 Prints one JSON object per case: wall time of ``network_crossover`` (the reference's ``Output.runtime``
 definition: host set-up and bookkeeping + solver-reported solve times), how much of it the sub-problem
@@ -19,7 +19,7 @@ from contextlib import redirect_stdout
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
 

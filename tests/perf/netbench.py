@@ -3,7 +3,7 @@
 library's stream, median of several repetitions), with the algorithmic bytes of SURVEY.md 8(d) and the
 CPU oracle timed beside each one on one host core.
 
-    python tools/netbench.py [--reps 20]
+    python tests/perf/netbench.py [--reps 20]
 
 K7  MCF flow indicators       config 4: V = 2^17, E = 2^20
 K9  ranking (argsort desc)    config 4 (E keys) and config 3 (S*D keys)
@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
 
