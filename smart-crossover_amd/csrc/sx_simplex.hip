@@ -692,16 +692,36 @@ inline unsigned grid1d(int64_t n, int64_t cap = 4096) {
     return static_cast<unsigned>(g < 1 ? 1 : g);
 }
 
+// per-solve device buffers: one arena allocation carved into 256-byte aligned pieces (a solve used to
+// make ~20 hipMalloc / hipFree pairs, milliseconds that a short warm-started re-solve does not have);
+// requests beyond the arena fall back to allocations of their own
 struct DevBufs {
     std::vector<void *> p;
+    char *arena = nullptr;
+    size_t arena_bytes = 0, used = 0;
     ~DevBufs() {
         for (void *q : p)
             if (q) (void)hipFree(q);
     }
+    int reserve(size_t bytes) {
+        void *d = nullptr;
+        SX_HIP(hipMalloc(&d, bytes));
+        p.push_back(d);
+        arena = static_cast<char *>(d);
+        arena_bytes = bytes;
+        used = 0;
+        return SX_OK;
+    }
     template <class T>
     int get(size_t count, T **out) {
+        const size_t want = (sizeof(T) * (count ? count : 1) + 255) & ~static_cast<size_t>(255);
+        if (arena && used + want <= arena_bytes) {
+            *out = reinterpret_cast<T *>(arena + used);
+            used += want;
+            return SX_OK;
+        }
         void *d = nullptr;
-        SX_HIP(hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+        SX_HIP(hipMalloc(&d, want));
         p.push_back(d);
         *out = static_cast<T *>(d);
         return SX_OK;
@@ -787,6 +807,13 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     hipStream_t s = ctx->stream;
 
     DevBufs mem;
+    {
+        // everything below except a session-less inverse: 34 B per variable, 44 B per row, pricing partials
+        const size_t um = static_cast<size_t>(m), uN = static_cast<size_t>(N);
+        size_t bytes = 34 * uN + 48 * um + 24 * (static_cast<size_t>(SPX_GRID) + um / 64 + 64) + 32 * 256 + 4096;
+        if (!session) bytes += sizeof(double) * um * um + 256;
+        SX_TRY(mem.reserve(bytes));
+    }
     Spx P;
     P.m = m;
     P.n = n;
@@ -933,18 +960,26 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
         hipLaunchKernelGGL(k_spx_commit, dim3(1), dim3(1), 0, s, P);
     };
-    // a batch of 32 pivots = 192 small launches with fixed arguments: captured once into a hipGraph
-    // and replayed (pivots are launch-bound for small m); direct launches are the fallback
+    // a batch of 32 pivots = 192 small launches with fixed arguments: captured into a hipGraph and
+    // replayed (pivots are launch-bound for small m); direct launches are the fallback.  Capturing and
+    // instantiating costs milliseconds, more than a short warm-started re-solve takes altogether, so the
+    // graph is only built once a solve has gone through GRAPH_AFTER pivots by direct launches.
     const int batch = 32;
+    const int64_t GRAPH_AFTER = 256;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    if (ctx->opt_graph && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (int k = 0; k < batch; ++k) enqueue_pivot();
-        if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
-            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
-            exec = nullptr;
-    }
-    (void)hipGetLastError();
+    bool graph_tried = false;
+    auto build_graph = [&]() {
+        graph_tried = true;
+        if (!ctx->opt_graph) return;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int k = 0; k < batch; ++k) enqueue_pivot();
+            if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                exec = nullptr;
+        }
+        (void)hipGetLastError();
+    };
     struct GraphGuard {
         hipGraph_t &g;
         hipGraphExec_t &e;
@@ -954,9 +989,12 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         }
     } graph_guard{graph, exec};
 
+    int64_t direct_pivots = 0; // over both phases
     auto run_phase = [&](int64_t budget) -> int {
         int64_t done_iters = 0;
         while (true) {
+            if (!exec && !graph_tried && direct_pivots >= GRAPH_AFTER) build_graph();
+            if (!exec) direct_pivots += batch;
             if (exec) {
                 SX_HIP(hipGraphLaunch(exec, s));
             } else {
