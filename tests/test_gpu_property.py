@@ -144,3 +144,59 @@ def test_sub_problem_compaction_on_random_codes(ctx, seed, m, n, frac):
     assert np.array_equal(got.indptr, want_indptr)
     assert np.array_equal(got.indices, colmap[A.indices[kept]])
     assert bits_equal(got.data, A.data[kept])
+
+
+@settings(max_examples=60, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2 ** 31 - 1), m=st.integers(1, 24), n=st.integers(1, 40),
+       kind=st.sampled_from(["feasible", "degenerate", "free", "maybe_infeasible", "maybe_unbounded"]))
+def test_device_simplex_agrees_with_highs_on_random_small_lps(seed, m, n, kind):
+    """K16 against scipy's HiGHS on small LPs of every flavour: same status, same optimal value, and a
+    returned basis that certifies the vertex (primal and dual feasible, m basic variables)."""
+    from scipy.optimize import linprog
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.solver_caller.solving import solve_lp
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=min(1.0, 3.0 / max(n, 1) + 0.15), random_state=seed % (2 ** 31), format="csr")
+    A.data = np.round(rng.uniform(-3, 3, A.nnz) * 2) / 2                       # halves: plenty of ties
+    A.eliminate_zeros()
+    sense = np.where(rng.random(m) < 0.5, "<", "=")
+    l = np.zeros(n)
+    u = np.where(rng.random(n) < 0.4, np.round(rng.uniform(1, 5, n)), np.inf)
+    x0 = np.where(np.isinf(u), rng.integers(0, 4, n), np.minimum(rng.integers(0, 4, n), u)).astype(float)
+    c = np.round(rng.uniform(-2, 4, n) * 2) / 2
+    if kind == "free":
+        free = rng.random(n) < 0.3
+        l[free], u[free] = -np.inf, np.inf
+        c[free] = 0.0
+    slack = np.where(sense == "<", rng.integers(0, 3, m), 0).astype(float)
+    if kind == "degenerate":
+        slack[:] = 0.0
+        x0[rng.random(n) < 0.6] = 0.0
+    b = A @ x0 + slack
+    if kind == "maybe_infeasible":
+        b = b - np.where(sense == "=", rng.integers(0, 2, m) * 7.0, rng.integers(0, 2, m) * 50.0)
+    if kind == "maybe_unbounded":
+        c = c - 3.0
+    lp = GeneralLP(A, b, c, l, u, sense)
+    lt = sense == "<"
+    ref = linprog(c, A_ub=A[lt] if lt.any() else None, b_ub=b[lt] if lt.any() else None,
+                  A_eq=A[~lt] if (~lt).any() else None, b_eq=b[~lt] if (~lt).any() else None,
+                  bounds=[(None if np.isinf(a) else a, None if np.isinf(z) else z) for a, z in zip(l, u)], method="highs",
+                  options={"presolve": False})      # with presolve HiGHS may answer "infeasible" for "infeasible or unbounded"
+    out = solve_lp(lp, "HIP", "default", SolverSettings(log_console=0))
+    if ref.status == 0:
+        assert out.status == "OPTIMAL", (kind, m, n, seed)
+        assert out.obj_val == pytest.approx(ref.fun, rel=1e-7, abs=1e-7)
+        x, y, vb, cb = out.x, out.y, out.basis.vbasis, out.basis.cbasis
+        s_p = b - A @ x
+        assert np.all(np.abs(s_p[~lt]) <= 1e-6) and np.all(s_p[lt] >= -1e-6)
+        assert np.all(x >= l - 1e-6) and np.all(x <= u + 1e-6)
+        rc = c - A.T @ y
+        assert np.all(rc[vb == -1] >= -1e-6) and np.all(rc[vb == -2] <= 1e-6) and np.all(np.abs(rc[vb == -3]) <= 1e-6)
+        assert int(np.count_nonzero(vb == 0) + np.count_nonzero(cb == 0)) == m
+    elif ref.status == 2:
+        assert out.status == "INFEASIBLE", (kind, m, n, seed)
+    elif ref.status == 3:
+        assert out.status == "UNBOUNDED", (kind, m, n, seed)
