@@ -200,3 +200,31 @@ def test_device_simplex_agrees_with_highs_on_random_small_lps(seed, m, n, kind):
         assert out.status == "INFEASIBLE", (kind, m, n, seed)
     elif ref.status == 3:
         assert out.status == "UNBOUNDED", (kind, m, n, seed)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), S=st.integers(2, 14), D=st.integers(2, 14),
+       method=st.sampled_from(["tnet", "cnet_ot"]), solver=st.sampled_from(["HIP", "HGS"]))
+def test_network_crossover_reaches_the_ot_optimum(seed, S, D, method, solver):
+    """Whole network crossover on random small transport problems, re-solves on the device (with the
+    session that keeps the basis inverse across rounds) or in HiGHS: optimal cost, feasible plan."""
+    import io
+    from contextlib import redirect_stdout
+    from scipy.optimize import linprog
+    import workloads
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.ot(S, D, seed=seed)
+    ot = OptTransport(inst.s.copy(), inst.d.copy(), inst.M.copy())
+    mcf = ot.to_MCF()
+    ref = linprog(mcf.c, A_eq=mcf.A, b_eq=mcf.b, bounds=(0, None), method="highs")
+    assert ref.status == 0
+    with redirect_stdout(io.StringIO()):
+        out = network_crossover(inst.x, ot=ot, method=method, solver=solver, solver_settings=SolverSettings(log_console=0))
+    X = (out.x.reshape(S + 1, D + 1)[:S, :D] if method == "cnet_ot" else out.x.reshape(S, D))
+    assert np.allclose(X.sum(axis=1), inst.s, atol=1e-7) and np.allclose(X.sum(axis=0), inst.d, atol=1e-7)
+    assert np.all(X >= -1e-9)
+    assert float((X * inst.M).sum()) == pytest.approx(ref.fun, rel=1e-8, abs=1e-10)
+    assert np.count_nonzero(X > 1e-12) <= S + D - 1                               # a basic solution
