@@ -90,6 +90,43 @@ def crossover_host_path(cpu_budget_s: float):
             "index_sets_and_subproblem_match_cpu": True}
 
 
+def crossover_network():
+    """BASELINE metric, part 'crossover wall-time (ms)', network case: the whole ``network_crossover`` call
+    (TNET) on config 3 -- OT on the 28 x 28 grid, 784 x 784, 614,656 arcs -- from the inexact plan in host
+    memory to the optimal basis in host memory.  Once with every re-solve on the device (solver 'HIP': device
+    simplex with a session), once with the re-solves in HiGHS on the host cores (the stand-in for the
+    reference's Gurobi/CPLEX).  Warm process (second call); both reach the same optimal cost."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.config3()
+    S, D = inst.M.shape
+    out = {"workload": f"c3: optimal transport {S} x {D} (n = {S * D}), Manhattan grid cost, method tnet, host memory to host memory"}
+    costs = {}
+    for solver, key in (("HIP", "gpu_resident_ms"), ("HGS", "host_solver_ms")):
+        times = []
+        for _ in range(3):
+            ot = OptTransport(inst.s.copy(), inst.d.copy(), inst.M.copy())
+            t0 = time.perf_counter()
+            with redirect_stdout(io.StringIO()):
+                res = network_crossover(inst.x, ot=ot, method="tnet", solver=solver, solver_settings=SolverSettings(log_console=0))
+            times.append((time.perf_counter() - t0) * 1e3)
+        X = res.x.reshape(S, D)
+        if max(np.abs(X.sum(axis=1) - inst.s).max(), np.abs(X.sum(axis=0) - inst.d).max()) > 1e-9:
+            raise SystemExit(f"bench: network crossover ({solver}) returned an infeasible plan")
+        costs[solver] = float((X * inst.M).sum())
+        out[key] = float(np.median(times[1:]))
+        out[key.replace("_ms", "_first_call_ms")] = times[0]
+        out[f"simplex_iterations_{solver}"] = int(res.iter_count)
+    if abs(costs["HIP"] - costs["HGS"]) > 1e-9 * (1 + abs(costs["HGS"])):
+        raise SystemExit("bench: device and HiGHS re-solves disagree on the optimal transport cost")
+    out["optimal_cost"] = costs["HGS"]
+    out["speedup"] = out["host_solver_ms"] / out["gpu_resident_ms"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +337,7 @@ def main():
     crossover = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_crossover:
         crossover = crossover_host_path(args.cpu_seconds)
+        crossover = {"lp_c2_host_path": crossover, "network_c3": crossover_network()}
 
     if rank == 0:
         out = {
