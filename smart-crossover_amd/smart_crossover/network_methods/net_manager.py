@@ -95,11 +95,13 @@ class _SessionHolder:
     session = None
 
 
-def _tag_sub_problem(sub: MinCostFlow, col_ids: np.ndarray, holder: _SessionHolder) -> None:
-    """Stable identifiers of the sub-problem's columns (their index in the full problem) and the state
-    holder, as plain attributes the reference's dataclass does not have; only backends that look for
-    them (solver_caller/hip.py) are affected."""
+def _tag_sub_problem(sub: MinCostFlow, col_ids: np.ndarray, holder: _SessionHolder, dev=None) -> None:
+    """Stable identifiers of the sub-problem's columns (their index in the full problem), the state
+    holder and the device copy of the sub-matrix the gather kernel has just built (so a device backend
+    need not upload the host copy again), as plain attributes the reference's dataclass does not have;
+    only backends that look for them (solver_caller/hip.py) are affected."""
     sub.col_ids = np.asarray(col_ids, dtype=_I64)
+    sub._sx_device_matrix = dev
     sub.hip_session = holder
 
 
@@ -181,8 +183,7 @@ class MCFManagerStd:
         ctx.fixed_rhs(dA, ctx.to_device(code), u_dev, ctx.zeros(ncol, np.float64), ctx.to_device(np.asarray(self.mcf.b, float)),
                       b_sub)
         self.mcf_sub = MinCostFlow(A=sub.to_scipy(), b=b_sub.download(), c=self.mcf.c[non_fix], u=self.mcf.u[non_fix])
-        sub.free()
-        _tag_sub_problem(self.mcf_sub, non_fix, self._spx_holder)
+        _tag_sub_problem(self.mcf_sub, non_fix, self._spx_holder, sub)      # `sub` is freed with the sub-problem object
 
     def solve_subproblem(self, solver: str, solver_settings: SolverSettings) -> Output:
         method = "network_simplex" if solver == "CPL" else "default"
@@ -336,8 +337,7 @@ class OTManager:
         sub = ctx.gather_columns(self._resident.get(self.mcf.A), ctx.to_device(cols))
         M = np.asarray(self.ot.M.toarray() if sp.issparse(self.ot.M) else self.ot.M)
         out = MinCostFlow(A=sub.to_scipy(), b=self.mcf.b, c=M.flatten()[mask], u=self.mcf.u[mask])
-        sub.free()
-        _tag_sub_problem(out, cols, self._spx_holder)
+        _tag_sub_problem(out, cols, self._spx_holder, sub)                   # `sub` is freed with `out`
         return out
 
     def solve_subproblem(self, solver: str, solver_settings: SolverSettings) -> Output:

@@ -47,7 +47,7 @@ class HipCaller(SolverCaller):
     def read_genlp(self, genlp: GeneralLP) -> None:
         self._load(genlp.A, genlp.b, genlp.c, genlp.l, genlp.u, np.asarray(genlp.sense) == "<")
         self._resident = getattr(genlp, "_sx_resident", None)
-        self._col_ids = self._session_holder = None
+        self._col_ids = self._session_holder = self._dev_matrix = None
 
     def read_stdlp(self, stdlp: StandardLP) -> None:
         self._load(stdlp.A, stdlp.b, stdlp.c, stdlp.l, stdlp.u, np.zeros(np.asarray(stdlp.b).size, dtype=bool))
@@ -56,6 +56,7 @@ class HipCaller(SolverCaller):
         # and a holder in which the device simplex keeps its basis inverse from one round to the next
         self._col_ids = getattr(stdlp, "col_ids", None)
         self._session_holder = getattr(stdlp, "hip_session", None)
+        self._dev_matrix = getattr(stdlp, "_sx_device_matrix", None)
 
     def get_A(self) -> sp.csr_matrix:
         return self._A
@@ -88,8 +89,13 @@ class HipCaller(SolverCaller):
         ctx = default_context()
         m, n = self._A.shape
         res = getattr(self, "_resident", None)
-        dA = res.A if res is not None and res.A.shape == (m, n) and res.A.handle is not None else ctx.matrix(self._A)
-        own = res is None or dA is not res.A
+        given = getattr(self, "_dev_matrix", None)
+        if given is not None and given.shape == (m, n) and given.handle is not None and given.ctx is ctx:
+            dA, own = given, False                      # built on the device by the manager's gather
+        elif res is not None and res.A.shape == (m, n) and res.A.handle is not None:
+            dA, own = res.A, False
+        else:
+            dA, own = ctx.matrix(self._A), True
         put = lambda v: ctx.to_device(np.ascontiguousarray(v, dtype=np.float64))   # noqa: E731
         d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
         d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
