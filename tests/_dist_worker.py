@@ -22,8 +22,34 @@ from oracle import net_path as N                # noqa: E402
 from smart_crossover import distributed as D    # noqa: E402
 
 
+def local_pass_device(sh):
+    """The same rank-local pass through the HIP kernels (SX_DIST_DEVICE=1; every rank on device 0)."""
+    from smart_crossover.hip import Context
+    ctx = Context(0)
+    n_loc, off = sh.n_block, sh.rank * sh.n_block
+    m_loc = sh.row_block.shape[0]
+    r0 = sh.rank * m_loc
+    dC, dR = ctx.column_shard(sh.col_block), ctx.row_shard(sh.row_block)
+    d_y, d_x = ctx.to_device(sh.y), ctx.to_device(sh.x)
+    s_d, code = ctx.empty(n_loc, np.float64), ctx.empty(n_loc, np.uint8)
+    s_p, flag = ctx.empty(m_loc, np.float64), ctx.empty(m_loc, np.uint8)
+    ctx.score_columns(dC, d_y, ctx.to_device(sh.c), ctx.to_device(sh.x[off:off + n_loc]), ctx.to_device(sh.l),
+                      ctx.to_device(sh.u), 1e-3, s_d, code)
+    ctx.score_rows(dR, d_x, ctx.to_device(sh.b), ctx.to_device(sh.y[r0:r0 + m_loc]), 1e-3, s_p, flag)
+    res = ctx.price(dC, d_y, ctx.to_device(sh.c), ctx.to_device(np.full(n_loc, -1, dtype=np.int8)), N.RC_TOL, None)
+    mn, am, bad = ctx.read_price(res)
+    code_h, flag_h = code.download(), flag.download()
+    counts = torch.tensor([int(ctx.where(code, 1).size), int(ctx.where(code, 2).size), int(ctx.where(flag, 0xFF).size)],
+                          dtype=torch.int64)
+    out = (code_h, flag_h, (float(mn), int(am), int(bad)), counts, s_d.download())
+    ctx.close()
+    return out
+
+
 def local_pass(sh):
     """What one rank computes from its column block and its row block."""
+    if os.environ.get("SX_DIST_DEVICE") == "1":
+        return local_pass_device(sh)
     n_loc, off = sh.n_block, sh.rank * sh.n_block
     x_loc = sh.x[off:off + n_loc]
     s_d = sh.c - sh.col_block.T @ sh.y
