@@ -11,9 +11,11 @@
 // (m <= 16384 -> 2 GiB) and turns FTRAN / the pivot row / the update into streaming kernels:
 //
 //   price        rc_j = c_j - a_j^T y for all structurals -- the same sequential CSC segment walk
-//                as K1/K10 -- plus the logicals; Dantzig rule (Bland's rule after 100 consecutive
-//                degenerate pivots); block partials + one selecting workgroup
-//   ftran        d = Binv a_q: linear combination of the few columns of Binv that a_q touches
+//                as K1/K10 -- plus the logicals, in one launch; Dantzig rule (Bland's rule after 100
+//                consecutive degenerate pivots); one partial per workgroup
+//   ftran        every workgroup reduces the partials to the entering column q (same deterministic
+//                reduction everywhere, no extra launch), then d = Binv a_q: linear combination of the
+//                few columns of Binv that a_q touches
 //   ratio        bounded ratio test incl. the entering variable's own bound flip; one workgroup,
 //                wavefront min-reductions, ties to the larger pivot (Bland: to the smaller index)
 //   update       x_B -= t*dir*d;  y += (rc_q/d_r) * rho_r;  Binv -= dhat rho_r^T   (rank one, the
@@ -25,6 +27,9 @@
 // of infeasible basic logicals and minimises their distance to feasibility; a warm basis
 // (Gurobi-style codes) is installed by pivoting its structural columns into the identity, picking
 // the largest available pivot each time, and is dropped if it turns out singular or infeasible.
+// A session (sx_simplex_session_*) keeps Binv between the solves of a column-generation sequence:
+// when the warm basis is exactly the basis the kept inverse belongs to (columns matched through
+// caller-supplied stable ids), it is installed without any pivot.
 //
 // Multi-GPU note: with columns sharded, `price` partials are per rank and the selection becomes the
 // all-gather + lexicographic min of smart_crossover/distributed.py (one small exchange per pivot);
