@@ -310,6 +310,21 @@ int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const
                          const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
                          double *x, double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
 
+/* ------------------------------------------------------------------ entropic OT warm start
+ * The step before the OT crossover in the reference's driver (scripts/run_network_crossover.py:95-97:
+ * sinkhorn(ot.s, ot.d, ot.M, reg=10, numItermax=1000) from the third-party package POT, absent and
+ * unpinned -> parity unpinned; published algorithm: Sinkhorn-Knopp scaling, oracle/sinkhorn.py).
+ * a[S], b[D] marginals, M[S*D] cost (row-major), all device.  Outputs (device, any may be NULL):
+ * plan[S*D] = (u .* exp(-M/reg)) .* v, u_out[S], v_out[D].  Blocking. */
+typedef struct sx_sinkhorn_result {
+    int64_t iters;  /* completed iterations */
+    int64_t status; /* 0 iteration limit, 1 marginal violation < stop_thr, 2 numerical breakdown (previous pair kept) */
+    double err;     /* last tested || plan^T 1 - b ||_2 (tested at iterations 0, 10, 20, ...) */
+} sx_sinkhorn_result;
+int sx_sinkhorn_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *a, const double *b, const double *M,
+                    double reg, int64_t max_iter, double stop_thr, double *plan, double *u_out, double *v_out,
+                    sx_sinkhorn_result *result);
+
 /* Session: keeps the basis inverse of the last solve on the device so that the next solve of a
  * column-generation sequence (network_methods/algorithms.py:105-139: same rows, more columns, warm basis
  * = previous optimal basis) starts from it instead of re-installing the basis pivot by pivot.

@@ -252,6 +252,13 @@ class Context:
     def simplex_session(self) -> "SimplexSession":
         return SimplexSession(self)
 
+    def sinkhorn(self, S, D, a, b, M, reg, max_iter=1000, stop_thr=1e-9, plan=None, u=None, v=None) -> "_l.SinkhornResult":
+        """Entropic OT warm start (blocking); device pointers in and out."""
+        res = _l.SinkhornResult()
+        _l.check(self._lib.sx_sinkhorn_dev(self.handle, int(S), int(D), _ptr(a), _ptr(b), _ptr(M), float(reg),
+                                           int(max_iter), float(stop_thr), _ptr(plan), _ptr(u), _ptr(v), C.byref(res)))
+        return res
+
     def x_real(self, n, x, l, u, out, apply_floor: bool = True) -> None:
         _l.check(self._lib.sx_x_real_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), int(bool(apply_floor)),
                                          _ptr(out)))

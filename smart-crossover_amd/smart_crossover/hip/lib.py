@@ -45,6 +45,10 @@ class SimplexResult(C.Structure):
                 ("warm_start_used", C.c_int64), ("obj", C.c_double), ("max_violation", C.c_double)]
 
 
+class SinkhornResult(C.Structure):
+    _fields_ = [("iters", C.c_int64), ("status", C.c_int64), ("err", C.c_double)]
+
+
 _vp = C.c_void_p
 _i64 = C.c_int64
 _dbl = C.c_double
@@ -104,6 +108,8 @@ PROTOTYPES = {
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
     "sx_simplex_solve_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                     C.POINTER(SimplexResult)]),
+    "sx_sinkhorn_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,
+                               C.POINTER(SinkhornResult)]),
     "sx_simplex_session_create": (_int, [_vp, C.POINTER(_vp)]),
     "sx_simplex_session_destroy": (_int, [_vp]),
     "sx_simplex_solve_session_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp,

@@ -1,0 +1,88 @@
+"""GPU: entropic OT warm start (sx_sinkhorn_dev) against the restatement of POT's sinkhorn_knopp
+(oracle/sinkhorn.py; POT itself is absent -> parity unpinned, see the oracle's header).  Floating point:
+the two matrix-vector products sum in a different order than numpy's BLAS, so plans agree to a relative
+1e-9, not bit for bit; the tolerance is stated where it is used."""
+import numpy as np
+import pytest
+
+from oracle import sinkhorn as OS
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def marginals(S, D, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.random(S) + 0.05
+    b = rng.random(D) + 0.05
+    a /= a.sum()
+    b /= b.sum()
+    return a, b
+
+
+@pytest.mark.parametrize("S,D,seed,reg,iters", [(12, 15, 0, 2.0, 1000), (1, 7, 1, 1.0, 50), (9, 1, 2, 1.0, 50),
+                                                (100, 130, 3, 5.0, 1000), (257, 64, 4, 3.0, 37)])
+def test_plan_matches_the_restated_algorithm(S, D, seed, reg, iters):
+    from smart_crossover.sinkhorn import sinkhorn
+    a, b = marginals(S, D, seed)
+    M = np.random.default_rng(seed + 10).integers(0, 20, size=(S, D)).astype(float)
+    want, log = OS.sinkhorn_knopp(a, b, M, reg, numItermax=iters)
+    got, glog = sinkhorn(a, b, M, reg, numItermax=iters, log=True)
+    assert got.shape == (S, D)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(glog["u"], log["u"], rtol=RTOL)
+    np.testing.assert_allclose(glog["v"], log["v"], rtol=RTOL)
+    # the stopping test fires at iterations 0, 10, 20, ...: the counts may differ by one test interval at most
+    assert abs(glog["niter"] - log["iters"]) <= 10
+    if glog["niter"] == log["iters"]:
+        assert glog["err"] == pytest.approx(log["err"], rel=1e-6, abs=1e-15)
+
+
+def test_config3_warm_start_feeds_the_crossover():
+    """Grid cost of config 3 with the reference's parameters (reg = 10, 1000 iterations): the plan has
+    the right marginals, matches the restatement, and TNET started from it reaches the optimal cost."""
+    import io
+    from contextlib import redirect_stdout
+    from scipy.optimize import linprog
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.sinkhorn import sinkhorn
+    from smart_crossover.solver_caller.caller import SolverSettings
+    M = workloads.grid_cost(12).astype(float)               # 144 x 144 keeps the reference LP solve small
+    S = D = M.shape[0]
+    a, b = marginals(S, D, 9)
+    want, log = OS.sinkhorn_knopp(a, b, M, 10.0, numItermax=1000)
+    got, glog = sinkhorn(a, b, M, reg=10, numItermax=1000, log=True)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-300)
+    assert np.abs(got.sum(axis=0) - b).max() < 1e-8 and glog["niter"] <= 1000
+    ot = OptTransport(a.copy(), b.copy(), M.copy())
+    mcf = ot.to_MCF()
+    ref = linprog(mcf.c, A_eq=mcf.A, b_eq=mcf.b, bounds=(0, None), method="highs")
+    with redirect_stdout(io.StringIO()):
+        out = network_crossover(got.flatten(), ot=ot, method="tnet", solver="HIP", solver_settings=SolverSettings(log_console=0))
+    X = out.x.reshape(S, D)
+    assert float((X * M).sum()) == pytest.approx(ref.fun, rel=1e-8)
+    assert np.allclose(X.sum(axis=1), a, atol=1e-8) and np.allclose(X.sum(axis=0), b, atol=1e-8)
+
+
+def test_breakdown_keeps_the_previous_pair():
+    """Costs so large that exp(-M/reg) underflows to 0 make K^T u vanish: POT restores the previous
+    scaling pair and stops with a warning; so does the device."""
+    from smart_crossover.sinkhorn import sinkhorn
+    a = np.array([0.5, 0.2, 0.3])
+    b = np.array([0.25, 0.75])
+    M = np.full((3, 2), 1e6)
+    want, log = OS.sinkhorn_knopp(a, b, M, 1.0, numItermax=100)
+    assert log["breakdown"] and log["iters"] == 0
+    with pytest.warns(UserWarning):
+        got, glog = sinkhorn(a, b, M, 1.0, numItermax=100, log=True)
+    assert glog["niter"] == 0
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+
+
+def test_bad_shapes_raise():
+    from smart_crossover.sinkhorn import sinkhorn
+    with pytest.raises(ValueError):
+        sinkhorn(np.ones(3) / 3, np.ones(4) / 4, np.zeros((4, 3)), 1.0)
