@@ -115,3 +115,28 @@ def test_config5_scoring_pass_properties(ctx):
     assert abs(lhs - rhs) <= 1e-9 * (abs(rhs) + np.sum(np.abs(sd1)))
     dC.free()
     dR.free()
+
+
+@pytest.mark.parametrize("method", ["tnet", "cnet_ot"])
+def test_config3_network_crossover_device_resident_equals_host_solver(method):
+    """Config 3 (OT 784 x 784, 614,656 arcs) through the whole network crossover, once with the re-solves
+    on the device and once in HiGHS: same optimal cost, a feasible basic plan, and the device path reuses
+    the kept basis inverse in every round after the first."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import OptTransport
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.config3()
+    S, D = inst.M.shape
+    costs = {}
+    for solver in ("HIP", "HGS"):
+        ot = OptTransport(inst.s.copy(), inst.d.copy(), inst.M.copy())
+        with redirect_stdout(io.StringIO()) as text:
+            out = network_crossover(inst.x, ot=ot, method=method, solver=solver, solver_settings=SolverSettings(log_console=0))
+        assert "Column generation fails" not in text.getvalue()
+        X = (out.x.reshape(S + 1, D + 1)[:S, :D] if method == "cnet_ot" else out.x.reshape(S, D))
+        assert np.abs(X.sum(axis=1) - inst.s).max() < 1e-9 and np.abs(X.sum(axis=0) - inst.d).max() < 1e-9
+        assert X.min() >= -1e-12 and np.count_nonzero(X > 1e-13) <= S + D - 1
+        costs[solver] = float((X * inst.M).sum())
+    assert costs["HIP"] == pytest.approx(costs["HGS"], rel=1e-9)
