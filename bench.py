@@ -208,11 +208,12 @@ def main():
     idx_low, idx_up, idx_row = ctx.empty(n_loc, np.int64), ctx.empty(n_loc, np.int64), ctx.empty(m_loc, np.int64)
     vb = ctx.to_device(np.full(n_loc, -1, dtype=np.int8))
     if world > 1:
-        t_counts = torch.zeros(3, dtype=torch.int64, device="cuda")
-        t_price = torch.zeros(24, dtype=torch.uint8, device="cuda")
-        t_gather = torch.zeros(24 * world, dtype=torch.uint8, device="cuda")
-        counts = ctx.wrap(t_counts.data_ptr(), 3, np.int64, owner=t_counts)
-        price = ctx.wrap(t_price.data_ptr(), 24, np.uint8, owner=t_price)
+        # one 48-byte record per rank and step: pricing record (24 B) + the three set sizes (3 x int64),
+        # exchanged by ONE all-gather; every rank reduces the gathered records itself
+        t_rec = torch.zeros(48, dtype=torch.uint8, device="cuda")
+        t_gather = torch.zeros(48 * world, dtype=torch.uint8, device="cuda")
+        price = ctx.wrap(t_rec.data_ptr(), 24, np.uint8, owner=t_rec)
+        counts = ctx.wrap(t_rec.data_ptr() + 24, 3, np.int64, owner=t_rec)
     else:
         counts = ctx.empty(3, np.int64)
         price = ctx.empty(24, np.uint8)
@@ -244,15 +245,11 @@ def main():
         if timed:
             ctx.marker(5 * i + 4)
         if world > 1 and not rehearse:
-            dist.all_gather_into_tensor(t_gather, t_price)
-            dist.all_reduce(t_counts)
+            dist.all_gather_into_tensor(t_gather, t_rec)
         elif rehearse:
-            cpu_gather = torch.empty(24 * world, dtype=torch.uint8)
-            dist.all_gather_into_tensor(cpu_gather, t_price.cpu())
+            cpu_gather = torch.empty(48 * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(cpu_gather, t_rec.cpu())
             t_gather.copy_(cpu_gather)
-            cpu_counts = t_counts.cpu()
-            dist.all_reduce(cpu_counts)
-            t_counts.copy_(cpu_counts)
 
     def fence():
         if world > 1:
@@ -306,11 +303,12 @@ def main():
     if world > 1:
         from smart_crossover import distributed as D
         raw = t_gather.cpu().numpy().tobytes()
-        recs = [D.unpack_price(raw[r * 24:(r + 1) * 24]) for r in range(world)]
+        recs = [D.unpack_price(raw[r * 48:r * 48 + 24]) for r in range(world)]
         mn, am, bad = D.reduce_price_records(recs, [r * n_loc for r in range(world)])
+        cnts = np.sum([np.frombuffer(raw[r * 48 + 24:(r + 1) * 48], dtype=np.int64) for r in range(world)], axis=0)
     else:
         mn, am, bad = ctx.read_price(price)
-    cnts = counts.download()
+        cnts = counts.download()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -346,7 +344,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "rows": m, "cols_per_gpu": n_loc, "cols_total": n_tot,
                        "nnz_per_gpu": int(nnz_loc), "step": "K1 score_columns + K2 score_rows + 3x select_indices + K10 price"
-                                                            + (" + all_gather(24B) + all_reduce(3xi64)" if world > 1 else ""),
+                                                            + (" + all_gather(48 B: pricing record + 3 set sizes)" if world > 1 else ""),
                        "parallelism": f"column/row blocks over {world} GPU(s)"},
             "roofline": {"kernel": "k_score_columns", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
