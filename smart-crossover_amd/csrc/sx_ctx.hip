@@ -288,32 +288,6 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
         SX_TRY(check_ptr(csc_colptr, n, nnz, "csc_colptr"));
         SX_TRY(check_idx(csc_row, nnz, m, "csc_row"));
     }
-    std::vector<int64_t> cptr;
-    std::vector<int32_t> crow;
-    std::vector<double> cval;
-    if (!have_csc) {
-        // stable counting sort by column == row-major walk order inside every column
-        try {
-            cptr.assign(static_cast<size_t>(n) + 1, 0);
-            crow.resize(static_cast<size_t>(nnz));
-            cval.resize(static_cast<size_t>(nnz));
-        } catch (const std::bad_alloc &) {
-            sx_set_error("out of host memory building CSC");
-            return SX_ERR_NOMEM;
-        }
-        for (int64_t k = 0; k < nnz; ++k) cptr[static_cast<size_t>(csr_col[k]) + 1]++;
-        for (int64_t j = 0; j < n; ++j) cptr[j + 1] += cptr[j];
-        std::vector<int64_t> next(cptr.begin(), cptr.end() - 1);
-        for (int64_t i = 0; i < m; ++i)
-            for (int64_t k = csr_rowptr[i]; k < csr_rowptr[i + 1]; ++k) {
-                int64_t dst = next[csr_col[k]]++;
-                crow[dst] = static_cast<int32_t>(i);
-                cval[dst] = csr_val[k];
-            }
-        csc_colptr = cptr.data();
-        csc_row = crow.data();
-        csc_val = cval.data();
-    }
     sx_matrix *A = new (std::nothrow) sx_matrix();
     if (!A) {
         sx_set_error("out of host memory");
@@ -326,11 +300,17 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
     int rc = SX_OK;
     if ((rc = upload_padded(ctx, csr_rowptr, m + 1, &A->csr_ptr)) == SX_OK &&
         (rc = upload_padded(ctx, csr_col, nnz, &A->csr_idx)) == SX_OK &&
-        (rc = upload_padded(ctx, csr_val, nnz, &A->csr_val)) == SX_OK &&
-        (rc = upload_padded(ctx, csc_colptr, n + 1, &A->csc_ptr)) == SX_OK &&
-        (rc = upload_padded(ctx, csc_row, nnz, &A->csc_idx)) == SX_OK &&
-        (rc = upload_padded(ctx, csc_val, nnz, &A->csc_val)) == SX_OK) {
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (rc = upload_padded(ctx, csr_val, nnz, &A->csr_val)) == SX_OK) {
+        if (have_csc) {
+            if ((rc = upload_padded(ctx, csc_colptr, n + 1, &A->csc_ptr)) == SX_OK &&
+                (rc = upload_padded(ctx, csc_row, nnz, &A->csc_idx)) == SX_OK)
+                rc = upload_padded(ctx, csc_val, nnz, &A->csc_val);
+        } else {
+            // stable transposition on the device (sx_transpose.hip): per-column entries in row-major walk order
+            rc = sx_transpose_dev(ctx, m, n, nnz, A->csr_ptr, A->csr_idx, A->csr_val, &A->csc_ptr, &A->csc_idx,
+                                  &A->csc_val);
+        }
+        if (rc == SX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
             sx_set_error("stream sync failed after matrix upload");
             rc = SX_ERR_HIP;
         }

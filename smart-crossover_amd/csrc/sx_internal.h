@@ -97,6 +97,10 @@ int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int
 // tiles per window load for A's column walk under ctx's "window" option (0 = plain walk)
 int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out);
 
+// stable CSR -> CSC transposition of device arrays (sx_transpose.hip); outputs are owned by the caller
+int sx_transpose_dev(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int32_t *col,
+                     const double *val, int64_t **colptr_out, int32_t **row_out, double **val_out);
+
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
                    int64_t *ntiles_out);
 // exclusive scan of in[0..n) into out[0..n] (out[n] = total); uses ctx->ws (sx_compact.hip)

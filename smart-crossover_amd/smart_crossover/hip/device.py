@@ -333,15 +333,19 @@ class DeviceMatrix:
         rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
         col = np.ascontiguousarray(A.indices, dtype=np.int32)
         val = np.ascontiguousarray(A.data, dtype=np.float64)
-        if csc is None:
-            csc = A.tocsc()          # scipy's csr_tocsc is the same stable counting sort the library uses
-        colptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
-        row = np.ascontiguousarray(csc.indices, dtype=np.int32)
-        cval = np.ascontiguousarray(csc.data, dtype=np.float64)
         h = C.c_void_p()
-        _l.check(ctx._lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rowptr.ctypes.data, col.ctypes.data,
-                                           val.ctypes.data, colptr.ctypes.data, row.ctypes.data, cval.ctypes.data,
-                                           C.byref(h)))
+        if csc is None:
+            # the library derives the CSC layout on the device: the stable transposition, i.e. what
+            # scipy's csr_tocsc would give, without seconds of host work on a large matrix
+            _l.check(ctx._lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rowptr.ctypes.data, col.ctypes.data,
+                                               val.ctypes.data, None, None, None, C.byref(h)))
+        else:
+            colptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
+            row = np.ascontiguousarray(csc.indices, dtype=np.int32)
+            cval = np.ascontiguousarray(csc.data, dtype=np.float64)
+            _l.check(ctx._lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rowptr.ctypes.data, col.ctypes.data,
+                                               val.ctypes.data, colptr.ctypes.data, row.ctypes.data, cval.ctypes.data,
+                                               C.byref(h)))
         self.handle = h
         self.shape = (m, n)
         self.nnz = int(A.nnz)
