@@ -14,6 +14,7 @@
 // ||b|| <= tol) are those of the reference's pinned scipy.
 #include "sx_internal.h"
 #include "sx_segwalk.h"
+#include "sx_window.h"
 
 #include <cmath>
 
@@ -95,6 +96,41 @@ __global__ __launch_bounds__(SX_WG) void k_cg_at(const CgState *st, const int64_
         if (valid) {
             const double s = scale[j];
             out[j] = (s * s) * acc[0];
+        }
+    }
+}
+
+// the same pass behind the LDS operand window (sx_window.h): grid-stride over runs of RUN tiles
+template <int RUN>
+__global__ __launch_bounds__(SX_WG) void k_cg_at_lw(const CgState *st, const int64_t *__restrict__ tiles,
+                                                    int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
+                                                    const int64_t *__restrict__ colptr,
+                                                    const int32_t *__restrict__ rowidx,
+                                                    const double *__restrict__ val, int64_t m,
+                                                    const double *__restrict__ in,
+                                                    const double *__restrict__ scale, double *__restrict__ out) {
+    if (st->done) return;
+    __shared__ sx_walk_lds<1, SXL_CHUNK> lds;
+    __shared__ double win[SXL_CAP];
+    const int64_t nruns = (ntiles + RUN - 1) / RUN;
+    int64_t r, r_end, r_step;
+    walk_range(nruns, swizzle, r, r_end, r_step);
+    for (; r < r_end; r += r_step) {
+        const int64_t t0 = r * RUN;
+        const int64_t t1 = (t0 + RUN < ntiles) ? t0 + RUN : ntiles;
+        const int64_t wlo = win_lo[(t0 + t1 - 1) >> 1];
+        __syncthreads(); // the previous run's gathers are done with the window
+        sx_window_fill(win, in, wlo, m);
+        __syncthreads();
+        for (int64_t t = t0; t < t1; ++t) {
+            double acc[1];
+            int64_t j;
+            bool valid;
+            sx_segwalk<1, SXL_CHUNK>(tiles, t, colptr, rowidx, val, sx_stage_win{in, win, wlo}, lds, j, valid, acc);
+            if (valid) {
+                const double s = scale[j];
+                out[j] = (s * s) * acc[0];
+            }
         }
     }
 }
@@ -316,6 +352,10 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     int64_t gv64 = ((m > n ? m : n) + 4 * SX_WG - 1) / (4 * SX_WG);
     const int gv = static_cast<int>(gv64 < 1 ? 1 : (gv64 > 1024 ? 1024 : gv64));
 
+    // column pass behind the LDS operand window when the matrix's auto rule (or the option) says so; the
+    // table is built here, outside any graph capture
+    int win_run = 0;
+    SX_TRY(sx_window_run_csc(ctx, A, &win_run));
     // workspace: state | partial_pq[CG_GRID] | partial_rr[CG_GRID] | z r p q [m] | w atz [n]
     const size_t off_state = 0;
     const size_t off_ppq = 256;
@@ -332,6 +372,17 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     double *r = z + m, *p = r + m, *q = p + m, *w = q + m, *atz = w + n;
     hipStream_t s = ctx->stream;
 
+    auto launch_at = [&](const double *in, const double *scale, double *out) { // out = scale^2 .* (A^T in)
+        if (win_run >= 4)
+            hipLaunchKernelGGL((k_cg_at_lw<4>), dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
+                               A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, m, in, scale, out);
+        else if (win_run >= 1)
+            hipLaunchKernelGGL((k_cg_at_lw<1>), dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
+                               A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, m, in, scale, out);
+        else
+            hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT, A->csc_ptr,
+                               A->csc_idx, A->csc_val, in, scale, out);
+    };
     SX_HIP(hipMemsetAsync(st, 0, sizeof(CgState), s));
     // b = A (xa^2 .* c) -> r ; rho0 = b.b
     hipLaunchKernelGGL(k_cg_scale_c, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, w);
@@ -355,8 +406,7 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     bool finished = trivial;
     if (!trivial && !(bnrm < tol * bnrm)) { // scipy tests ||r|| < atol before the first iteration too
         auto enqueue_iteration = [&](int par) {
-            hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
-                               A->csc_ptr, A->csc_idx, A->csc_val, p, xa, w);
+            launch_at(p, xa, w);
             hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
                                A->csr_ptr, A->csr_idx, A->csr_val, w, xs, p, q, ppq);
             hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, gA, p, q, z, r, prr);
@@ -414,8 +464,7 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     // (dividing xa^2 (A^T z) by xa would break on xa = 0), so w becomes a vector of ones first.
     hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, st, tol * bnrm, 0); // re-arm the kernels
     hipLaunchKernelGGL(k_cg_ones, dim3(gv), dim3(SX_WG), 0, s, n, w);
-    hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT,
-                       A->csc_ptr, A->csc_idx, A->csc_val, z, w, atz);
+    launch_at(z, w, atz);
     hipLaunchKernelGGL(k_cg_proj_cols, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, atz, ppq, proj_cols);
     hipLaunchKernelGGL(k_cg_proj_rows, dim3(gv), dim3(SX_WG), 0, s, m, xs, cs, z, prr, proj_rows);
     hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, st, ppq, gv, prr, gv);
