@@ -312,40 +312,60 @@ __global__ __launch_bounds__(SX_WG) void k_select_count(const uint8_t *__restric
     if (threadIdx.x == 0) block_count[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// exclusive scan of block_count in place (single workgroup), total -> *count_out
+// exclusive scan of block_count in place (single workgroup), total -> *count_out.  Every lane owns a
+// run of consecutive counts (serial prefix), the run totals are scanned by wave shuffles and four wave
+// totals: six barriers per 4096 counts instead of a Hillis-Steele ladder.
+constexpr int SCAN_RUN = 16;
 __global__ __launch_bounds__(SX_WG) void k_select_scan(int64_t *__restrict__ block_count,
                                                        int64_t nblocks,
                                                        int64_t *__restrict__ count_out) {
-    __shared__ long long s[SX_WG];
+    __shared__ long long wtot[SX_WG / 64];
     __shared__ long long carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int64_t b0 = 0; b0 < nblocks; b0 += SX_WG) {
-        const int64_t b = b0 + threadIdx.x;
-        const long long mine = (b < nblocks) ? block_count[b] : 0;
-        s[threadIdx.x] = mine;
-        __syncthreads();
-        for (int o = 1; o < SX_WG; o <<= 1) { // Hillis-Steele inclusive scan
-            long long add = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0;
-            __syncthreads();
-            s[threadIdx.x] += add;
-            __syncthreads();
+    for (int64_t b0 = 0; b0 < nblocks; b0 += SX_WG * SCAN_RUN) {
+        const int64_t first = b0 + static_cast<int64_t>(threadIdx.x) * SCAN_RUN;
+        long long v[SCAN_RUN];
+        long long run = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_RUN; ++k) {
+            v[k] = (first + k < nblocks) ? block_count[first + k] : 0;
+            run += v[k];
         }
-        const long long incl = s[threadIdx.x];
-        if (b < nblocks) block_count[b] = carry + incl - mine;
+        long long incl = run; // inclusive scan of the run totals inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == SX_WG - 1) carry += incl;
+        long long before = carry + incl - run;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+#pragma unroll
+        for (int k = 0; k < SCAN_RUN; ++k) {
+            if (first + k < nblocks) block_count[first + k] = before;
+            before += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == SX_WG - 1) carry = before; // end of the last lane's run = total so far
         __syncthreads();
     }
     if (threadIdx.x == 0) *count_out = carry;
 }
 
+// The selected positions of a tile are first collected in LDS as 16-bit offsets, in order, and then
+// written out by all lanes with consecutive 8-byte stores (a lane writing its own run directly would
+// scatter every store instruction over up to 64 cache lines).
 __global__ __launch_bounds__(SX_WG) void k_select_write(const uint8_t *__restrict__ flags,
                                                         int64_t n, uint8_t mask,
                                                         const int64_t *__restrict__ block_off,
                                                         int64_t *__restrict__ idx_out) {
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * SEL_TILE +
-                          static_cast<int64_t>(threadIdx.x) * SEL_PER_THREAD;
+    __shared__ uint16_t off[SEL_TILE];
+    __shared__ int wsum[SX_WG / 64];
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * SEL_TILE;
+    const int64_t first = tile0 + static_cast<int64_t>(threadIdx.x) * SEL_PER_THREAD;
     uint32_t bits = (first < n) ? sel_load_mask(flags, n, first, mask) : 0u;
     const int mine = __popc(bits);
     // exclusive prefix of `mine` across the workgroup: wave scan + wave offsets
@@ -356,17 +376,23 @@ __global__ __launch_bounds__(SX_WG) void k_select_write(const uint8_t *__restric
         int t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    __shared__ int wsum[SX_WG / 64];
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    int64_t dst = block_off[blockIdx.x] + woff + incl - mine;
+    int woff = 0, total = 0;
+    for (int w = 0; w < SX_WG / 64; ++w) {
+        if (w < wave) woff += wsum[w];
+        total += wsum[w];
+    }
+    int k = woff + incl - mine;
+    const int base = threadIdx.x * SEL_PER_THREAD;
     while (bits) {
         const int t = __ffs(bits) - 1;
         bits &= bits - 1;
-        idx_out[dst++] = first + t;
+        off[k++] = static_cast<uint16_t>(base + t);
     }
+    __syncthreads();
+    const int64_t dst = block_off[blockIdx.x];
+    for (int q = threadIdx.x; q < total; q += SX_WG) idx_out[dst + q] = tile0 + off[q];
 }
 
 // ------------------------------------------------------------------------------------- K3
