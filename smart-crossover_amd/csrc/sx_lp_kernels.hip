@@ -202,10 +202,18 @@ __global__ __launch_bounds__(SX_WG) void k_price(
         double acc[1];
         int64_t j;
         bool valid;
-        sx_segwalk<1, CHUNK, NT>(tiles, t, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc);
+        double cj = 0.0;
+        int vbj = 0; // requested before the walk so that their latency hides under it
+        auto pre = [&](int64_t seg, bool ok) {
+            if (ok) {
+                cj = c[seg];
+                if (vbasis) vbj = vbasis[seg];
+            }
+        };
+        sx_segwalk<1, CHUNK, NT>(tiles, t, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre);
         if (valid) {
-            double rc = c[j] - acc[0];
-            if (vbasis && vbasis[j] == -2) rc = -rc;
+            double rc = cj - acc[0];
+            if (vbj == -2) rc = -rc;
             if (rc_out) rc_out[j] = rc;
             bad += (rc >= -tol) ? 0 : 1;
             if (rc == rc) price_combine(v, ix, rc, j); // NaN never becomes the minimum
@@ -245,10 +253,19 @@ __global__ __launch_bounds__(SX_WG) void k_price_lw(
             double acc[1];
             int64_t j;
             bool valid;
-            sx_segwalk<1, SXL_CHUNK, 0>(tiles, t, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, j, valid, acc);
+            double cj = 0.0;
+            int vbj = 0; // the epilogue's operands are requested before the walk (as in K1)
+            auto pre = [&](int64_t seg, bool ok) {
+                if (ok) {
+                    cj = c[seg];
+                    if (vbasis) vbj = vbasis[seg];
+                }
+            };
+            sx_segwalk<1, SXL_CHUNK, 0>(tiles, t, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, j, valid, acc,
+                                        pre);
             if (valid) {
-                double rc = c[j] - acc[0];
-                if (vbasis && vbasis[j] == -2) rc = -rc;
+                double rc = cj - acc[0];
+                if (vbj == -2) rc = -rc;
                 if (rc_out) rc_out[j] = rc;
                 bad += (rc >= -tol) ? 0 : 1;
                 if (rc == rc) price_combine(v, ix, rc, j);
