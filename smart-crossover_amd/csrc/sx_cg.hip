@@ -92,11 +92,12 @@ __global__ __launch_bounds__(SX_WG) void k_cg_at(const CgState *st, const int64_
         double acc[1];
         int64_t j;
         bool valid;
-        sx_segwalk<1, CG_CHUNK>(tiles, t, colptr, rowidx, val, StageDot{in}, lds, j, valid, acc);
-        if (valid) {
-            const double s = scale[j];
-            out[j] = (s * s) * acc[0];
-        }
+        double s = 0.0;
+        auto pre = [&](int64_t seg, bool ok) {
+            if (ok) s = scale[seg];
+        };
+        sx_segwalk<1, CG_CHUNK>(tiles, t, colptr, rowidx, val, StageDot{in}, lds, j, valid, acc, pre);
+        if (valid) out[j] = (s * s) * acc[0];
     }
 }
 
@@ -126,11 +127,12 @@ __global__ __launch_bounds__(SX_WG) void k_cg_at_lw(const CgState *st, const int
             double acc[1];
             int64_t j;
             bool valid;
-            sx_segwalk<1, SXL_CHUNK>(tiles, t, colptr, rowidx, val, sx_stage_win{in, win, wlo}, lds, j, valid, acc);
-            if (valid) {
-                const double s = scale[j];
-                out[j] = (s * s) * acc[0];
-            }
+            double s = 0.0;
+            auto pre = [&](int64_t seg, bool ok) {
+                if (ok) s = scale[seg];
+            };
+            sx_segwalk<1, SXL_CHUNK>(tiles, t, colptr, rowidx, val, sx_stage_win{in, win, wlo}, lds, j, valid, acc, pre);
+            if (valid) out[j] = (s * s) * acc[0];
         }
     }
 }
@@ -155,11 +157,17 @@ __global__ __launch_bounds__(SX_WG) void k_cg_a(const CgState *st, const int64_t
         double acc[1];
         int64_t i;
         bool valid;
-        sx_segwalk<1, CG_CHUNK>(tiles, t, rowptr, colidx, val, StageDot{w}, lds, i, valid, acc);
+        double s = 0.0, pi = 0.0; // epilogue operands requested before the walk
+        auto pre = [&](int64_t seg, bool ok) {
+            if (ok && p) {
+                s = xs[seg];
+                pi = p[seg];
+            }
+        };
+        sx_segwalk<1, CG_CHUNK>(tiles, t, rowptr, colidx, val, StageDot{w}, lds, i, valid, acc, pre);
         if (valid) {
             double qi = acc[0];
             if (p) {
-                const double s = xs[i], pi = p[i];
                 qi = qi + (s * s) * pi;
                 dot += pi * qi;
             } else {
