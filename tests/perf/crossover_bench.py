@@ -108,12 +108,12 @@ def run_ot(method, solver, limit):
     return rec
 
 
-def run_mcf(solver, limit):
+def run_mcf(solver, limit, V=None, E=None):
     from smart_crossover.formats import MinCostFlow
     from smart_crossover.network_methods.algorithms import network_crossover
     from smart_crossover.network_methods.net_manager import MCFManagerStd
     from smart_crossover.solver_caller.caller import SolverSettings
-    inst = workloads.config4()
+    inst = workloads.config4() if V is None else workloads.mcf(V, E, seed=3)
     mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
     V, E = inst.A.shape
     st = SolverSettings(log_console=0, timeLimit=limit)
@@ -123,7 +123,7 @@ def run_mcf(solver, limit):
         wall = time.perf_counter() - t0
     x = out.x[:E]
     rec = {
-        "case": "c4_cnet_mcf", "problem": f"MCF V = {V}, E = {E}", "solver": solver,
+        "case": "c4_cnet_mcf" if V == 2 ** 17 else "mcf_cnet_mcf", "problem": f"MCF V = {V}, E = {E}", "solver": solver,
         "wall_ms": wall * 1e3, "runtime_reported_ms": out.runtime.total_seconds() * 1e3,
         "solver_ms": clk.wall * 1e3, "host_path_ms": (wall - clk.wall) * 1e3, "subproblem_solves": clk.calls,
         "subproblem_columns": clk.sizes, "simplex_iterations": int(out.iter_count),
@@ -194,6 +194,10 @@ def main():
                 rec = run_ot("cnet_ot", args.solver, args.time_limit)
             elif case == "c4_cnet":
                 rec = run_mcf(args.solver, args.time_limit)
+            elif case == "mcf_4k":
+                rec = run_mcf(args.solver, args.time_limit, V=4096, E=32768)
+            elif case == "mcf_12k":
+                rec = run_mcf(args.solver, args.time_limit, V=12288, E=98304)
             elif case == "lp":
                 rec = run_lp(args.solver, args.time_limit)
             elif case == "lp_c2":
