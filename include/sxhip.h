@@ -61,12 +61,15 @@ int sx_device_count(int *count);
 int sx_ctx_create(int device, void *stream, sx_ctx **out);
 int sx_ctx_destroy(sx_ctx *ctx);
 int sx_ctx_sync(sx_ctx *ctx);
-/* Tuning knobs (performance only, never results): "xcd_swizzle" 0/1 (default 1), "nt_stream"
+/* Tuning knobs (performance only; the kernels of the scoring / pricing / CG path return identical bits
+ * under every setting, the simplex the same optimum up to rounding): "xcd_swizzle" 0/1 (default 1), "nt_stream"
  * (cache policy of the streamed entry loads: 0 plain [default], 1 non-temporal, 2/16/17/18 buffer loads
  * with nt / sc1 / sc0 sc1 / nt sc1), "chunk" 2048/4096 (default 4096), "window" (LDS operand window of the
  * column walk in K1/K10: -1 auto [default: decided per matrix from its index clustering on first use],
- * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch).  Unknown keys return
- * SX_ERR_INVALID. */
+ * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch),
+ * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
+ * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]).
+ * Unknown keys return SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
 int sx_ctx_device_info(sx_ctx *ctx, char *name, size_t name_len, int *cu_count, uint64_t *hbm_bytes);

@@ -94,6 +94,8 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_window = value < 0 ? -1 : static_cast<int>(value);
     } else if (!strcmp(key, "graph")) {
         ctx->opt_graph = value ? 1 : 0;
+    } else if (!strcmp(key, "spx_defer")) {
+        ctx->opt_spx_defer = value < 0 ? -1 : (value ? 1 : 0);
     } else {
         sx_set_error("unknown option '%s'", key);
         return SX_ERR_INVALID;

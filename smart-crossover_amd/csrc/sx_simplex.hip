@@ -13,14 +13,24 @@
 //   price        rc_j = c_j - a_j^T y for all structurals -- the same sequential CSC segment walk
 //                as K1/K10 -- plus the logicals, in one launch; Dantzig rule (Bland's rule after 100
 //                consecutive degenerate pivots); one partial per workgroup
-//   ftran        every workgroup reduces the partials to the entering column q (same deterministic
+//   ftran+ratio  every workgroup reduces the partials to the entering column q (same deterministic
 //                reduction everywhere, no extra launch), then d = Binv a_q: linear combination of the
-//                few columns of Binv that a_q touches
-//   ratio        bounded ratio test incl. the entering variable's own bound flip; one workgroup,
-//                wavefront min-reductions, ties to the larger pivot (Bland: to the smaller index)
-//   update       x_B -= t*dir*d;  y += (rc_q/d_r) * rho_r;  Binv -= dhat rho_r^T   (rank one, the
-//                only O(m^2) step: 16 m^2 bytes of HBM traffic per pivot)
+//                few columns of Binv that a_q touches.  Each lane owns one basis row and evaluates its
+//                entry of the bounded ratio test on the spot; one candidate per workgroup, and the
+//                workgroup that arrives last (ticket) reduces them under a strict total order (smaller
+//                step, then larger pivot -- Bland: smaller variable index --, then row) and decides
+//                between pivot and bound flip of the entering variable
+//   rho+update   rho = row r of the inverse;  x_B -= t*dir*d;  y += (rc_q/d_r) * rho; the last workgroup
+//                to arrive does the basis bookkeeping from values it loaded before the ticket
+//   inverse      Binv -= dhat rho^T is the only O(m^2) step (16 m^2 bytes of HBM traffic).  By default it
+//                is not done per pivot: the pairs (dhat_s, rho_s) of a batch of 32 pivots are kept
+//                (product form: Binv_now = Binv - sum_s dhat_s rho_s^T, so FTRAN and the pivot row need
+//                one extra pass over the pending columns, without any recurrence) and k_spx_fold applies
+//                them in one pass, in pivot order -- the same fma sequence per entry as 32 rank-one
+//                updates, 1/32 of their traffic ("spx_defer" 0 restores the update per pivot)
 //
+// A pivot is three launches, each a chain of dependent memory round trips of about a microsecond rather
+// than arithmetic; loads that do not depend on the entering column / pivot row are issued first.
 // Scalars (entering column, step, leaving row, flags) live in a device struct; every kernel is a
 // no-op once `done` is set, so the host enqueues pivots in batches of 32 and polls.  Every 64 pivots
 // x_B = Binv (b - N x_N) and y = Binv^T c_B are recomputed from scratch.  Phase 1 relaxes the bounds
@@ -47,6 +57,7 @@ constexpr int SPX_CHUNK = 4096;
 constexpr int SPX_GRID = 1024;   // price workgroups (= partials) at most
 constexpr double PIV_TOL = 1e-9; // smallest |pivot| accepted
 constexpr int BLAND_AFTER = 100;
+constexpr int SPX_DEFER = 32;    // pivots whose inverse updates are held back and folded in together
 
 enum : int { ST_BASIC = 0, ST_LOWER = -1, ST_UPPER = -2, ST_FREE = -3 };
 
@@ -72,6 +83,14 @@ struct Spx {
     int32_t *head;
     double *y, *d, *rho, *rhs, *b;
     double *Binv;
+    // deferred updates (product form inside a batch): eta columns, pivot rows of the inverse, pivot row ids
+    double *E, *R; // m x SPX_DEFER each, column s = pivot s of the batch
+    int32_t *er;   // row of pivot s, or -1 when slot s holds no update (bound flip, stopped)
+    // ratio test: one candidate per ftran workgroup (3 doubles + 2 ints each); arrival tickets of the
+    // two launches that end with a single-workgroup epilogue (ftran -> ratio, rho_update -> commit)
+    double *rt_val;
+    int32_t *rt_idx;
+    unsigned *tickets;
     SpxState *st;
     // pricing partials
     double *p_score, *p_rc;
@@ -126,6 +145,109 @@ __device__ __forceinline__ double score_of(int st, double rc, double lo, double 
     return (bland && s > 0.0) ? 1.0 : s;
 }
 
+// ------------------------------------------------------------------ ratio test pieces
+// candidate of the bounded ratio test: step length, |pivot|, pivot d_r, basis row, variable held by the row
+struct RatioCand {
+    double t, piv, dval;
+    int row, hk;
+};
+
+// strict total order: smaller step; then the larger pivot (Bland: the smaller variable index); then the row
+__device__ __forceinline__ bool cand_better(const RatioCand &a, const RatioCand &b, int bland) {
+    if (a.row < 0) return false;
+    if (b.row < 0) return true;
+    if (a.t != b.t) return a.t < b.t;
+    if (bland) return a.hk < b.hk;
+    if (a.piv != b.piv) return a.piv > b.piv;
+    return a.row < b.row;
+}
+
+// best candidate of the workgroup, valid in thread 0
+__device__ __forceinline__ RatioCand block_best_cand(RatioCand c, int bland, RatioCand *lds /* [SX_WG / 64] */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        RatioCand c2;
+        c2.t = __shfl_down(c.t, o, 64);
+        c2.piv = __shfl_down(c.piv, o, 64);
+        c2.dval = __shfl_down(c.dval, o, 64);
+        c2.row = __shfl_down(c.row, o, 64);
+        c2.hk = __shfl_down(c.hk, o, 64);
+        if (cand_better(c2, c, bland)) c = c2;
+    }
+    __syncthreads(); // lds may still be read from an earlier call
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < SX_WG / 64; ++w)
+            if (cand_better(lds[w], c, bland)) c = lds[w];
+    return c;
+}
+
+__device__ __forceinline__ void put_cand(const Spx &P, unsigned slot, const RatioCand &c) {
+    P.rt_val[3 * slot] = c.t;
+    P.rt_val[3 * slot + 1] = c.piv;
+    P.rt_val[3 * slot + 2] = c.dval;
+    P.rt_idx[2 * slot] = c.row;
+    P.rt_idx[2 * slot + 1] = c.hk;
+}
+
+__device__ __forceinline__ RatioCand get_cand(const Spx &P, unsigned slot) {
+    return RatioCand{P.rt_val[3 * slot], P.rt_val[3 * slot + 1], P.rt_val[3 * slot + 2], P.rt_idx[2 * slot],
+                     P.rt_idx[2 * slot + 1]};
+}
+
+// Every workgroup calls this once it has written its share; true in the one that arrives last, which then
+// sees what all others wrote (release fence before the ticket, acquire fence after it).  A dozen to a few
+// dozen workgroups take a ticket per launch -- unlike the m^2-sized update, where this was tried and lost.
+// With SEES_OTHERS false the fences are left out: for an epilogue that reads nothing the other workgroups
+// wrote and stores to no address they store to (it is then only ordered after their loads).
+template <bool SEES_OTHERS>
+__device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
+    __shared__ int is_last;
+    if (SEES_OTHERS) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (is_last) atomicExch(ticket, 0u); // ready for the next launch
+    }
+    __syncthreads();
+    if (SEES_OTHERS && is_last) __threadfence();
+    return is_last != 0;
+}
+
+// outcome of the ratio test for entering variable q (single lane): pivot row or bound flip, step, Bland switch
+// `range` = up[q] - lo[q] (inf unless the entering variable is boxed) and the run of degenerate steps so far
+// come in as values loaded early in the launch: after the ticket only stores remain, no load round trips.
+__device__ __forceinline__ void finish_ratio(const Spx &P, const RatioCand &best, double range, int degenerate_run) {
+    SpxState *st = P.st;
+    const double best_t = (best.row >= 0) ? best.t : INFINITY;
+    if (!(best_t < INFINITY) && !(range < INFINITY)) {
+        st->done = 2; // unbounded ray
+        return;
+    }
+    double t;
+    if (range <= best_t) {
+        t = range;
+        st->flip = 1;
+        st->r = -1;
+        st->alpha = 1.0;
+    } else {
+        t = best_t;
+        st->flip = 0;
+        st->r = best.row;
+        st->alpha = best.dval;
+    }
+    st->t = t;
+    if (t <= 1e-12) {
+        st->degenerate_run = degenerate_run + 1;
+        if (degenerate_run + 1 > BLAND_AFTER) st->bland = 1;
+    } else {
+        st->degenerate_run = 0;
+        st->bland = 0;
+    }
+}
+
 // ------------------------------------------------------------------ pricing
 // one launch prices everything: workgroups [0, gP) walk the structural columns, [gP, gridDim) the logicals
 __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__restrict__ tiles, int64_t ntiles,
@@ -166,19 +288,50 @@ __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__res
 // ------------------------------------------------------------------ ftran: d = Binv * a_q
 // In the pivot loop (q_override < 0) every workgroup first repeats the selection of the entering column
 // from the pricing partials -- a deterministic reduction, so all arrive at the same q without another
-// launch -- and workgroup 0 records it in the state.
+// launch -- and workgroup 0 records it in the state; the ratio test follows in the same launch.
+// With q_override >= 0 (installing a warm basis) column q_override is transformed and given the row, among
+// those still held by a logical, where it has the largest entry (crash_cb: the warm basis' row codes,
+// rows whose logical it keeps basic are taken only if nothing else works; crash_slot: where a deferred
+// update is recorded, or -1).
 __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__restrict__ colptr,
                                                      const int32_t *__restrict__ rowidx,
-                                                     const double *__restrict__ val, int q_override, int nslots) {
+                                                     const double *__restrict__ val, int q_override, int nslots,
+                                                     int pending, const int8_t *__restrict__ crash_cb,
+                                                     int crash_slot) {
     __shared__ double sh_s[SX_WG / 64], sh_rc[SX_WG / 64];
     __shared__ long long sh_j[SX_WG / 64];
+    __shared__ double coef[SPX_DEFER];
+    __shared__ RatioCand sh_c[SX_WG / 64];
     int64_t q = q_override;
+    const bool fuse = q_override < 0; // pivot loop: the ratio test rides along
+    int dirq = 1, bland = 0, degenerate_run = 0;
+    RatioCand best{INFINITY, 0.0, 0.0, -1, 0};
+    // A pivot is a chain of dependent memory round trips, about a microsecond each, and little else; so
+    // everything that does not depend on the entering column is requested here, before it is known: this
+    // lane's row of the pending eta columns, the variable its basis row holds, which slots are live.
+    const int64_t m = P.m;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; // one row per lane (host: grid = m / SX_WG)
+    const bool have = i < m;
+    const int hk = have ? P.head[i] : 0;
+    double ev[SPX_DEFER];
+#pragma unroll
+    for (int s = 0; s < SPX_DEFER; ++s) ev[s] = (s < pending && have) ? P.E[i + s * m] : 0.0;
+    const bool live = threadIdx.x < pending && P.er[threadIdx.x] >= 0;
+    if (threadIdx.x < SPX_DEFER) coef[threadIdx.x] = 0.0;
+    double xi = 0.0, lok = 0.0, upk = 0.0, range = INFINITY;
     if (q_override < 0) {
         SpxState *st = P.st;
         if (st->done) return;
+        bland = st->bland;
+        degenerate_run = st->degenerate_run;
         double s = 0.0, rc = 0.0;
         long long j = -1;
         for (int k = threadIdx.x; k < nslots; k += SX_WG) better(s, j, rc, P.p_score[k], P.p_idx[k], P.p_rc[k]);
+        if (have) { // second round trip, under way while the selection is reduced
+            xi = P.x[hk];
+            lok = P.lo[hk];
+            upk = P.up[hk];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double s2 = __shfl_down(s, o, 64), r2 = __shfl_down(rc, o, 64);
@@ -196,6 +349,11 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
         rc = sh_rc[0];
         for (int w = 1; w < SX_WG / 64; ++w) better(s, j, rc, sh_s[w], sh_j[w], sh_rc[w]);
         const bool none = j < 0 || s <= 0.0;
+        if (!none) {
+            const int stq = P.status[j];
+            range = P.up[j] - P.lo[j];
+            dirq = (stq == ST_LOWER) ? 1 : (stq == ST_UPPER) ? -1 : (rc < 0 ? 1 : -1);
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (none) {
                 st->done = 1;
@@ -203,187 +361,308 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
             } else {
                 st->q = static_cast<int>(j);
                 st->rc_q = rc;
-                const int stq = P.status[j];
-                st->dir = (stq == ST_LOWER) ? 1 : (stq == ST_UPPER) ? -1 : (rc < 0 ? 1 : -1);
+                st->dir = dirq;
             }
         }
         if (none) return;
         q = j;
     }
-    const int64_t m = P.m;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
-         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
-        double acc = 0.0;
-        if (q >= P.n) {
-            acc = P.Binv[i + (q - P.n) * m];
-        } else {
-            for (int64_t e = colptr[q]; e < colptr[q + 1]; ++e) acc = fma(val[e], P.Binv[i + rowidx[e] * m], acc);
+    // updates of this batch not yet folded into Binv: Binv_now = Binv - sum_s E_s R_s^T, hence
+    // d = Binv a_q - sum_s (R_s . a_q) E_s ; the entries of a_q are walked once, for both sums (the column
+    // index is uniform: scalar loads)
+    const int qs = __builtin_amdgcn_readfirstlane(static_cast<int>(q));
+    const int64_t sm = static_cast<int64_t>(threadIdx.x) * m; // lane s < pending: column s of R
+    double acc = 0.0, cs = 0.0;
+    if (qs >= P.n) {
+        const int64_t k = qs - P.n;
+        if (have) acc = P.Binv[i + k * m];
+        if (live) cs = P.R[k + sm];
+    } else {
+        const int64_t e0 = colptr[qs], e1 = colptr[qs + 1];
+#pragma unroll 4
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t ri = rowidx[e];
+            const double v = val[e];
+            if (have) acc = fma(v, P.Binv[i + ri * m], acc);
+            if (live) cs = fma(v, P.R[ri + sm], cs);
         }
+    }
+    if (pending > 0) {
+        if (live) coef[threadIdx.x] = cs;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SPX_DEFER; ++s) acc = fma(-coef[s], ev[s], acc); // slots >= pending: 0 * 0
+    }
+    if (have) {
         P.d[i] = acc;
-    }
-}
-
-// ------------------------------------------------------------------ ratio test (one workgroup)
-__global__ __launch_bounds__(1024) void k_spx_ratio(Spx P) {
-    SpxState *st = P.st;
-    if (st->done) return;
-    const int q = st->q, dir = st->dir, bland = st->bland;
-    double best_t = INFINITY, best_piv = 0.0;
-    int best_r = -1;
-    for (int i = threadIdx.x; i < P.m; i += 1024) {
-        const double delta = dir * P.d[i];
-        const int k = P.head[i];
-        const double xi = P.x[k];
-        double ratio = INFINITY;
-        if (delta > PIV_TOL) {
-            if (P.lo[k] > -INFINITY) ratio = (xi - P.lo[k]) / delta;
-        } else if (delta < -PIV_TOL) {
-            if (P.up[k] < INFINITY) ratio = (P.up[k] - xi) / (-delta);
+        if (fuse) { // this row's entry in the ratio test
+            const double delta = dirq * acc;
+            double ratio = INFINITY;
+            if (delta > PIV_TOL) {
+                if (lok > -INFINITY) ratio = (xi - lok) / delta;
+            } else if (delta < -PIV_TOL) {
+                if (upk < INFINITY) ratio = (upk - xi) / (-delta);
+            }
+            if (ratio < 0.0) ratio = 0.0; // slightly infeasible basic: degenerate step
+            if (ratio < INFINITY) best = RatioCand{ratio, fabs(delta), acc, static_cast<int>(i), hk};
+        } else if (hk >= P.n && fabs(acc) > PIV_TOL) { // crash: row still held by a logical, usable pivot
+            const double pref = (crash_cb && crash_cb[hk - P.n] == 0) ? 1e-6 : 1.0;
+            best = RatioCand{-fabs(acc) * pref, 0.0, acc, static_cast<int>(i), hk}; // smallest t = largest weight
         }
-        if (ratio < 0.0) ratio = 0.0; // slightly infeasible basic: degenerate step
-        if (ratio < INFINITY) {
-            const double piv = fabs(delta);
-            bool take;
-            if (best_r < 0) take = true;
-            else if (bland) take = ratio < best_t || (ratio == best_t && k < P.head[best_r]);
-            else take = ratio < best_t || (ratio == best_t && piv > best_piv);
-            if (take) {
-                best_t = ratio;
-                best_piv = piv;
-                best_r = i;
+    }
+    if (!fuse) {
+        best = block_best_cand(best, 0, sh_c);
+        if (threadIdx.x == 0) put_cand(P, blockIdx.x, best);
+        if (!last_block_arrives<true>(P.tickets)) return;
+        best = RatioCand{INFINITY, 0.0, 0.0, -1, 0};
+        for (unsigned p = threadIdx.x; p < gridDim.x; p += SX_WG) {
+            const RatioCand c = get_cand(P, p);
+            if (cand_better(c, best, 0)) best = c;
+        }
+        best = block_best_cand(best, 0, sh_c);
+        if (threadIdx.x == 0) { // the column takes row best.row; flip == 1 makes k_spx_rho skip a column without one
+            SpxState *st = P.st;
+            const int br = best.row;
+            st->done = 0;
+            st->q = qs;
+            st->r = br;
+            st->flip = (br < 0) ? 1 : 0;
+            st->alpha = (br >= 0) ? best.dval : 1.0;
+            if (crash_slot >= 0) P.er[crash_slot] = br;
+            if (br >= 0) {
+                P.status[best.hk] = ST_LOWER;
+                P.x[best.hk] = 0.0;
+                P.status[qs] = ST_BASIC;
+                P.head[br] = qs;
             }
         }
+        return;
     }
-    __shared__ double st_t[16], st_p[16];
-    __shared__ int st_r[16];
-    for (int o = 32; o > 0; o >>= 1) {
-        const double t2 = __shfl_down(best_t, o, 64), p2 = __shfl_down(best_piv, o, 64);
-        const int r2 = __shfl_down(best_r, o, 64);
-        bool take = false;
-        if (r2 >= 0) {
-            if (best_r < 0) take = true;
-            else if (bland) take = t2 < best_t || (t2 == best_t && P.head[r2] < P.head[best_r]);
-            else take = t2 < best_t || (t2 == best_t && p2 > best_piv);
-        }
-        if (take) {
-            best_t = t2;
-            best_piv = p2;
-            best_r = r2;
-        }
+    // ratio test without a launch of its own: one candidate per workgroup, and the workgroup that arrives
+    // last reduces them (strict total order -> the result does not depend on which one that is)
+    best = block_best_cand(best, bland, sh_c);
+    if (threadIdx.x == 0) put_cand(P, blockIdx.x, best);
+    if (!last_block_arrives<true>(P.tickets)) return;
+    best = RatioCand{INFINITY, 0.0, 0.0, -1, 0};
+    for (unsigned p = threadIdx.x; p < gridDim.x; p += SX_WG) {
+        const RatioCand c = get_cand(P, p);
+        if (cand_better(c, best, bland)) best = c;
     }
-    if ((threadIdx.x & 63) == 0) {
-        st_t[threadIdx.x >> 6] = best_t;
-        st_p[threadIdx.x >> 6] = best_piv;
-        st_r[threadIdx.x >> 6] = best_r;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) {
-            const int r2 = st_r[w];
-            if (r2 < 0) continue;
-            bool take;
-            if (best_r < 0) take = true;
-            else if (bland) take = st_t[w] < best_t || (st_t[w] == best_t && P.head[r2] < P.head[best_r]);
-            else take = st_t[w] < best_t || (st_t[w] == best_t && st_p[w] > best_piv);
-            if (take) {
-                best_t = st_t[w];
-                best_piv = st_p[w];
-                best_r = r2;
-            }
-        }
-        const double range = P.up[q] - P.lo[q]; // inf unless the entering variable is boxed
-        if (!(best_t < INFINITY) && !(range < INFINITY)) {
-            st->done = 2; // unbounded ray
-            return;
-        }
-        if (range <= best_t) {
-            st->flip = 1;
-            st->t = range;
-            st->r = -1;
-            st->alpha = 1.0;
-        } else {
-            st->flip = 0;
-            st->t = best_t;
-            st->r = best_r;
-            st->alpha = P.d[best_r];
-        }
-        if (st->t <= 1e-12) {
-            if (++st->degenerate_run > BLAND_AFTER) st->bland = 1;
-        } else {
-            st->degenerate_run = 0;
-            st->bland = 0;
-        }
-    }
+    best = block_best_cand(best, bland, sh_c);
+    if (threadIdx.x == 0) finish_ratio(P, best, range, degenerate_run);
 }
 
 // rho = row r of Binv (strided gather), before Binv changes
-__global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P) {
+//
+// With `pending` updates of the batch not yet folded in, row r of the current inverse is
+// Binv[r,:] - sum_s E_s[r] R_s[:]; with slot >= 0 the update of this pivot is not applied to Binv but
+// recorded as the pair (E_slot = dhat, R_slot = rho) for k_spx_fold.
+__device__ __forceinline__ void rho_weights(const Spx &P, int64_t r, int pending, double *w /* LDS */) {
+    if (pending > 0) {
+        if (threadIdx.x < pending) {
+            const int64_t s = threadIdx.x;
+            w[s] = (P.er[s] >= 0) ? P.E[r + s * P.m] : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double rho_entry(const Spx &P, int64_t r, int64_t k, int pending, const double *w) {
+    double v = P.Binv[r + k * P.m];
+#pragma unroll 8
+    for (int s = 0; s < pending; ++s) v = fma(-w[s], P.R[k + s * P.m], v);
+    return v;
+}
+
+__device__ __forceinline__ void record_update(const Spx &P, int64_t r, int64_t i, int slot, double rho_i, double alpha) {
+    const double inv = 1.0 / alpha;
+    P.R[i + slot * P.m] = rho_i;
+    P.E[i + slot * P.m] = (i == r) ? (alpha - 1.0) * inv : P.d[i] * inv;
+}
+
+__global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int pending, int slot) {
+    __shared__ double w[SPX_DEFER];
     const SpxState *st = P.st;
     if (st->done || st->flip) return;
     const int64_t m = P.m, r = st->r;
+    const double alpha = st->alpha;
+    rho_weights(P, r, pending, w);
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < m;
-         k += static_cast<int64_t>(gridDim.x) * SX_WG)
-        P.rho[k] = P.Binv[r + k * m];
-}
-
-// pivot loop: rho as above and, in the same launch, x_B -= t*dir*d ;  y += (rc_q / alpha) * rho
-// (element i needs only its own rho[i])
-__global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P) {
-    const SpxState *st = P.st;
-    if (st->done) return;
-    const double step = st->t * st->dir;
-    const bool pivot = !st->flip;
-    const double mult = pivot ? st->rc_q / st->alpha : 0.0;
-    const int64_t m = P.m, r = st->r;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
-         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
-        const int k = P.head[i];
-        P.x[k] = P.x[k] - step * P.d[i];
-        if (pivot) {
-            const double rho_i = P.Binv[r + i * m];
-            P.rho[i] = rho_i;
-            P.y[i] = P.y[i] + mult * rho_i;
-        }
+         k += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double rho_k = rho_entry(P, r, k, pending, w);
+        P.rho[k] = rho_k;
+        if (slot >= 0) record_update(P, r, k, slot, rho_k, alpha);
     }
 }
 
-// basis bookkeeping of one pivot (single lane)
-__device__ __forceinline__ void spx_commit(const Spx &P) {
+// what the basis bookkeeping of a pivot needs to know, read before the rows are updated so that the
+// bookkeeping itself -- run by the workgroup that finishes last -- only stores
+struct CommitView {
+    int q, dir, flip, r, k;    // entering variable, its direction, bound flip?, pivot row, leaving variable
+    double t, alpha, xq, loq, upq, lok, upk;
+    long long iters, n_relaxed;
+    int relaxed_k, row_lt_k;
+};
+
+__device__ __forceinline__ CommitView commit_view(const Spx &P) {
+    const SpxState *st = P.st;
+    CommitView v;
+    v.q = st->q;
+    v.dir = st->dir;
+    v.flip = st->flip;
+    v.r = st->r;
+    v.t = st->t;
+    v.alpha = st->alpha;
+    v.iters = st->iters;
+    v.n_relaxed = st->n_relaxed;
+    v.xq = P.x[v.q];
+    v.loq = P.lo[v.q];
+    v.upq = P.up[v.q];
+    v.k = v.flip ? 0 : P.head[v.r];
+    v.lok = v.upk = 0.0;
+    v.relaxed_k = v.row_lt_k = 0;
+    if (!v.flip) {
+        v.lok = P.lo[v.k];
+        v.upk = P.up[v.k];
+        v.relaxed_k = P.relaxed[v.k];
+        if (v.k >= P.n) v.row_lt_k = P.row_lt[v.k - P.n];
+    }
+    return v;
+}
+
+// basis bookkeeping of one pivot (single lane, after every row has been updated)
+__device__ __forceinline__ void spx_commit(const Spx &P, const CommitView &v, int slot) {
     SpxState *st = P.st;
-    if (st->done) return;
-    const int q = st->q;
-    P.x[q] = P.x[q] + st->dir * st->t;
-    if (st->flip) {
-        P.status[q] = (st->dir > 0) ? ST_UPPER : ST_LOWER;
-        P.x[q] = (st->dir > 0) ? P.up[q] : P.lo[q];
+    if (slot >= 0) P.er[slot] = v.flip ? -1 : v.r; // does the slot hold an update for k_spx_fold?
+    const int q = v.q;
+    if (v.flip) {
+        P.status[q] = (v.dir > 0) ? ST_UPPER : ST_LOWER;
+        P.x[q] = (v.dir > 0) ? v.upq : v.loq;
     } else {
-        const int r = st->r;
-        const int k = P.head[r];
-        const bool to_lower = st->dir * st->alpha > 0; // x_k was decreasing
-        if (P.relaxed[k]) { // a phase-1 logical that reached feasibility gets its true bounds back
-            const int64_t i = k - P.n;
+        P.x[q] = v.xq + v.dir * v.t;
+        const int k = v.k;
+        const bool to_lower = v.dir * v.alpha > 0; // x_k was decreasing
+        if (v.relaxed_k) { // a phase-1 logical that reached feasibility gets its true bounds back
             P.relaxed[k] = 0;
             P.lo[k] = 0.0;
-            P.up[k] = P.row_lt[i] ? INFINITY : 0.0;
+            P.up[k] = v.row_lt_k ? INFINITY : 0.0;
             P.cost[k] = 0.0;
             P.x[k] = 0.0;
             P.status[k] = ST_LOWER;
-            st->n_relaxed -= 1;
+            st->n_relaxed = v.n_relaxed - 1;
         } else {
             P.status[k] = to_lower ? ST_LOWER : ST_UPPER;
-            P.x[k] = to_lower ? P.lo[k] : P.up[k];
+            P.x[k] = to_lower ? v.lok : v.upk;
         }
         P.status[q] = ST_BASIC;
-        P.head[r] = q;
-        if (!(fabs(st->alpha) > PIV_TOL)) st->done = 3;
+        P.head[v.r] = q;
+        if (!(fabs(v.alpha) > PIV_TOL)) st->done = 3;
     }
-    st->iters += 1;
+    st->iters = v.iters + 1;
 }
 
-// The bookkeeping stays a launch of its own: folding it into the last workgroup of k_spx_update_binv
-// (ticket counter) was measured 3x slower overall -- thousands of atomics on one address cost far more
-// than the ~4 us launch they save.
-__global__ void k_spx_commit(Spx P) { spx_commit(P); }
+// pivot loop: rho as above and, in the same launch, x_B -= t*dir*d ;  y += (rc_q / alpha) * rho
+// (row i needs only its own rho[i]); the workgroup that finishes last does the basis bookkeeping.
+// One row per lane (host: grid = m / SX_WG), loads ordered by what they depend on, as in k_spx_ftran.
+__global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, int slot) {
+    __shared__ double w[SPX_DEFER];
+    const SpxState *st = P.st;
+    const int64_t m = P.m;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    const bool have = i < m;
+    // independent of the pivot row
+    const int hk = have ? P.head[i] : 0;
+    const double di = have ? P.d[i] : 0.0, yi = have ? P.y[i] : 0.0;
+    double rv[SPX_DEFER];
+#pragma unroll
+    for (int s = 0; s < SPX_DEFER; ++s) rv[s] = (s < pending && have) ? P.R[i + s * m] : 0.0;
+    const bool live = threadIdx.x < pending && P.er[threadIdx.x] >= 0;
+    if (threadIdx.x < SPX_DEFER) w[threadIdx.x] = 0.0;
+    if (st->done) {
+        if (slot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) P.er[slot] = -1; // nothing recorded in this slot
+        return;
+    }
+    const double step = st->t * st->dir;
+    const bool pivot = !st->flip;
+    const double alpha = st->alpha;
+    const double mult = pivot ? st->rc_q / alpha : 0.0;
+    const int64_t r = st->r;
+    // second round trip: needs the pivot row / this row's variable
+    CommitView view;
+    if (threadIdx.x == 0) view = commit_view(P);
+    const double xk = have ? P.x[hk] : 0.0;
+    double rho_i = (pivot && have) ? P.Binv[r + i * m] : 0.0;
+    if (pivot && pending > 0) {
+        if (live) w[threadIdx.x] = P.E[r + threadIdx.x * m];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SPX_DEFER; ++s) rho_i = fma(-w[s], rv[s], rho_i); // slots >= pending: 0 * 0
+    }
+    if (have) {
+        // the leaving variable is set to its bound by the bookkeeping, which may run in another workgroup:
+        // row r does not store to it, so no address is written from two workgroups
+        if (!(pivot && i == r)) P.x[hk] = xk - step * di;
+        if (pivot) {
+            P.rho[i] = rho_i;
+            P.y[i] = yi + mult * rho_i;
+            if (slot >= 0) {
+                const double inv = 1.0 / alpha;
+                P.R[i + slot * m] = rho_i;
+                P.E[i + slot * m] = (i == r) ? (alpha - 1.0) * inv : di * inv;
+            }
+        }
+    }
+    if (last_block_arrives<false>(P.tickets + 1) && threadIdx.x == 0) spx_commit(P, view, slot);
+}
+
+// Deferred form of the update below: the `cnt` recorded pairs of a batch go into the inverse in one pass,
+// Binv[i,k] -= sum_s E_s[i] R_s[k] (in pivot order, one fma per pair: the same arithmetic as `cnt` rank-one
+// updates, with 1/cnt of their HBM traffic).  A workgroup owns 256 rows x FOLD_COLS columns: each lane keeps
+// its row of E in registers, the R tile sits in LDS and is read as a broadcast.
+constexpr int FOLD_COLS = 64;
+__global__ __launch_bounds__(SX_WG) void k_spx_fold(Spx P, int cnt, int col_tiles) {
+    __shared__ double rt[SPX_DEFER][FOLD_COLS];
+    __shared__ int any_live;
+    const int64_t m = P.m;
+    if (threadIdx.x == 0) any_live = 0;
+    __syncthreads();
+    if (threadIdx.x < cnt && P.er[threadIdx.x] >= 0) any_live = 1; // benign race: all writers store 1
+    __syncthreads();
+    if (!any_live) return;
+    const int64_t rb = blockIdx.x / col_tiles, cb = blockIdx.x - rb * col_tiles;
+    const int64_t i = rb * SX_WG + threadIdx.x, k0 = cb * FOLD_COLS;
+    const int ncol = static_cast<int>((m - k0 < FOLD_COLS) ? (m - k0) : FOLD_COLS);
+    for (int e = threadIdx.x; e < SPX_DEFER * FOLD_COLS; e += SX_WG) {
+        const int s = e / FOLD_COLS, kk = e - s * FOLD_COLS;
+        rt[s][kk] = (s < cnt && kk < ncol && P.er[s] >= 0) ? P.R[k0 + kk + s * m] : 0.0;
+    }
+    double ev[SPX_DEFER];
+#pragma unroll
+    for (int s = 0; s < SPX_DEFER; ++s) ev[s] = (s < cnt && i < m) ? P.E[i + s * m] : 0.0;
+    __syncthreads();
+    if (i >= m) return;
+    // two columns at a time: two loads in flight and two independent fma chains per lane (no further
+    // unrolling: it would take the registers that keep several waves per SIMD resident)
+    double *col = P.Binv + i + k0 * m;
+    int kk = 0;
+#pragma unroll 1
+    for (; kk + 2 <= ncol; kk += 2, col += 2 * m) {
+        double v0 = col[0], v1 = col[m];
+#pragma unroll
+        for (int s = 0; s < SPX_DEFER; ++s) {
+            v0 = fma(-ev[s], rt[s][kk], v0);
+            v1 = fma(-ev[s], rt[s][kk + 1], v1);
+        }
+        col[0] = v0;
+        col[m] = v1;
+    }
+    if (kk < ncol) {
+        double v0 = col[0];
+#pragma unroll
+        for (int s = 0; s < SPX_DEFER; ++s) v0 = fma(-ev[s], rt[s][kk], v0);
+        col[0] = v0;
+    }
+}
 
 // Binv -= dhat * rho^T with dhat_i = d_i/alpha (i != r), dhat_r = (alpha - 1)/alpha
 __global__ __launch_bounds__(SX_WG) void k_spx_update_binv(Spx P) {
@@ -454,59 +733,6 @@ __global__ __launch_bounds__(SX_WG) void k_spx_apply_vbasis(Spx P, const int8_t 
         } else if (code == ST_LOWER && P.lo[k] > -INFINITY) {
             P.status[k] = ST_LOWER;
             P.x[k] = P.lo[k];
-        }
-    }
-}
-
-// warm start: row for structural column q among rows still held by a logical (largest |d_i|)
-__global__ __launch_bounds__(1024) void k_spx_crash_pick(Spx P, int q, const int8_t *__restrict__ cb) {
-    SpxState *st = P.st;
-    double best = 0.0;
-    int br = -1;
-    for (int i = threadIdx.x; i < P.m; i += 1024) {
-        const int k = P.head[i];
-        if (k < P.n) continue;                         // row already given to a structural
-        const double a = fabs(P.d[i]);
-        // prefer rows whose logical the warm basis marks non-basic; others only if nothing else works
-        const double pref = (cb && cb[k - P.n] == 0) ? 1e-6 : 1.0;
-        const double w = a * pref;
-        if (a > PIV_TOL && (br < 0 || w > best)) {
-            best = w;
-            br = i;
-        }
-    }
-    __shared__ double sb[16];
-    __shared__ int sr[16];
-    for (int o = 32; o > 0; o >>= 1) {
-        const double b2 = __shfl_down(best, o, 64);
-        const int r2 = __shfl_down(br, o, 64);
-        if (r2 >= 0 && (br < 0 || b2 > best)) {
-            best = b2;
-            br = r2;
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        sb[threadIdx.x >> 6] = best;
-        sr[threadIdx.x >> 6] = br;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (sr[w] >= 0 && (br < 0 || sb[w] > best)) {
-                best = sb[w];
-                br = sr[w];
-            }
-        st->done = 0;
-        st->q = q;
-        st->r = br;
-        st->flip = (br < 0) ? 1 : 0; // flip == 1 makes rho / update_binv skip this column
-        st->alpha = (br >= 0) ? P.d[br] : 1.0;
-        if (br >= 0) {
-            const int k = P.head[br];
-            P.status[k] = ST_LOWER;
-            P.x[k] = 0.0;
-            P.status[q] = ST_BASIC;
-            P.head[br] = q;
         }
     }
 }
@@ -810,6 +1036,9 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     }
     if (max_iter <= 0) max_iter = 50 * (m + n) + 1000;
     hipStream_t s = ctx->stream;
+    // measured (profiles/r01/spx_bench.txt): holding the updates back is as fast as the rank-one update per
+    // pivot at 200-1000 rows and 1.3x / 2.2x faster at 2000 / 4000, so "auto" means on
+    const bool defer = ctx->opt_spx_defer != 0;
 
     DevBufs mem;
     {
@@ -817,6 +1046,8 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         const size_t um = static_cast<size_t>(m), uN = static_cast<size_t>(N);
         size_t bytes = 34 * uN + 48 * um + 24 * (static_cast<size_t>(SPX_GRID) + um / 64 + 64) + 32 * 256 + 4096;
         if (!session) bytes += sizeof(double) * um * um + 256;
+        if (defer) bytes += 2 * sizeof(double) * um * SPX_DEFER + 1024;
+        bytes += 32 * (um / SX_WG + 2) + 1024; // ratio candidates, tickets
         SX_TRY(mem.reserve(bytes));
     }
     Spx P;
@@ -848,6 +1079,24 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     } else {
         SX_TRY(mem.get(static_cast<size_t>(m) * static_cast<size_t>(m), &P.Binv));
     }
+    P.E = P.R = nullptr;
+    P.er = nullptr;
+    if (defer) {
+        SX_TRY(mem.get(static_cast<size_t>(m) * SPX_DEFER, &P.E));
+        SX_TRY(mem.get(static_cast<size_t>(m) * SPX_DEFER, &P.R));
+        SX_TRY(mem.get(static_cast<size_t>(SPX_DEFER), &P.er));
+        // unused slots take part in the fold with a zero factor: they must hold finite numbers
+        SX_HIP(hipMemsetAsync(P.E, 0, sizeof(double) * static_cast<size_t>(m) * SPX_DEFER, s));
+        SX_HIP(hipMemsetAsync(P.R, 0, sizeof(double) * static_cast<size_t>(m) * SPX_DEFER, s));
+        SX_HIP(hipMemsetAsync(P.er, 0xff, sizeof(int32_t) * SPX_DEFER, s));
+    }
+    {
+        const size_t ratio_slots = static_cast<size_t>(grid1d(m));
+        SX_TRY(mem.get(3 * ratio_slots, &P.rt_val));
+        SX_TRY(mem.get(2 * ratio_slots, &P.rt_idx));
+        SX_TRY(mem.get(2, &P.tickets));
+        SX_HIP(hipMemsetAsync(P.tickets, 0, 2 * sizeof(unsigned), s));
+    }
     SX_TRY(mem.get(1, &P.st));
     const int gP = static_cast<int>(A->n_csc_tiles < SPX_GRID ? (A->n_csc_tiles > 0 ? A->n_csc_tiles : 1) : SPX_GRID);
     const int gL = static_cast<int>(grid1d(m, 64));
@@ -867,6 +1116,11 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
                            A->csr_idx, A->csr_val);
         hipLaunchKernelGGL(k_spx_xb, dim3(grid1d(m * 4, 2048)), dim3(1024), 0, s, P); // one workgroup per 64 rows
         if (with_y) hipLaunchKernelGGL(k_spx_btran, dim3(grid1d(m * 64)), dim3(SX_WG), 0, s, P);
+    };
+    const int fold_col_tiles = static_cast<int>((m + FOLD_COLS - 1) / FOLD_COLS);
+    const unsigned fold_grid = static_cast<unsigned>(((m + SX_WG - 1) / SX_WG) * fold_col_tiles);
+    auto fold = [&](int cnt) {
+        hipLaunchKernelGGL(k_spx_fold, dim3(fold_grid), dim3(SX_WG), 0, s, P, cnt, fold_col_tiles);
     };
     double host_meas[3] = {0, 0, 0};
     auto measure = [&]() -> int {
@@ -937,14 +1191,20 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     if (!reused) cold_start(1);
     if (vbasis_in && !reused) {
         hipLaunchKernelGGL(k_spx_apply_vbasis, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in);
+        int slot = 0;
         for (int64_t j = 0; j < n; ++j) {
             if (vb[static_cast<size_t>(j)] != ST_BASIC) continue;
             hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val,
-                               static_cast<int>(j), 0);
-            hipLaunchKernelGGL(k_spx_crash_pick, dim3(1), dim3(1024), 0, s, P, static_cast<int>(j), cbasis_in);
-            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P);
-            hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
+                               static_cast<int>(j), 0, defer ? slot : 0, cbasis_in, defer ? slot : -1);
+            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P, defer ? slot : 0, defer ? slot : -1);
+            if (!defer) {
+                hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
+            } else if (++slot == SPX_DEFER) {
+                fold(slot);
+                slot = 0;
+            }
         }
+        if (defer && slot > 0) fold(slot);
         hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
         refresh(true);
         SX_TRY(measure());
@@ -956,20 +1216,24 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     // ---- phases
     SpxState host;
     memset(&host, 0, sizeof(host));
-    auto enqueue_pivot = [&]() {
+    const int batch = SPX_DEFER;
+    // pivot number k of a batch; with deferred updates it sees k pending pairs and records its own in slot k
+    auto enqueue_pivot = [&](int k) {
         hipLaunchKernelGGL(k_spx_price, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
                            A->csc_idx, A->csc_val, opt_tol, gP);
-        hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1, gP + gL);
-        hipLaunchKernelGGL(k_spx_ratio, dim3(1), dim3(1024), 0, s, P);
-        hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P);
-        hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
-        hipLaunchKernelGGL(k_spx_commit, dim3(1), dim3(1), 0, s, P);
+        hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1, gP + gL,
+                           defer ? k : 0, static_cast<const int8_t *>(nullptr), -1);
+        hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P, defer ? k : 0, defer ? k : -1);
+        if (!defer) hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
     };
-    // a batch of 32 pivots = 192 small launches with fixed arguments: captured into a hipGraph and
+    auto enqueue_batch = [&]() {
+        for (int k = 0; k < batch; ++k) enqueue_pivot(k);
+        if (defer) fold(batch);
+    };
+    // a batch of 32 pivots = 96 small launches (+ the fold) with fixed arguments: captured into a hipGraph and
     // replayed (pivots are launch-bound for small m); direct launches are the fallback.  Capturing and
     // instantiating costs milliseconds, more than a short warm-started re-solve takes altogether, so the
     // graph is only built once a solve has gone through GRAPH_AFTER pivots by direct launches.
-    const int batch = 32;
     const int64_t GRAPH_AFTER = 256;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -978,7 +1242,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         graph_tried = true;
         if (!ctx->opt_graph) return;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int k = 0; k < batch; ++k) enqueue_pivot();
+            enqueue_batch();
             if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
                 hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 exec = nullptr;
@@ -1003,7 +1267,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             if (exec) {
                 SX_HIP(hipGraphLaunch(exec, s));
             } else {
-                for (int k = 0; k < batch; ++k) enqueue_pivot();
+                enqueue_batch();
             }
             done_iters += batch;
             SX_HIP(hipGetLastError());

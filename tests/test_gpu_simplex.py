@@ -53,6 +53,39 @@ def test_cold_start_matches_highs(m, n, k, seed):
     assert out.iter_count > 0
 
 
+@pytest.fixture
+def inverse_update_mode():
+    """Sets the 'spx_defer' option of the shared context for one test and restores the default."""
+    from smart_crossover.hip import default_context
+    ctx = default_context()
+
+    def choose(mode):
+        ctx.set_option("spx_defer", mode)
+    yield choose
+    ctx.set_option("spx_defer", -1)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("m,n,k,seed", [(27, 51, 2, 2024), (45, 130, 3, 12), (200, 700, 5, 2), (700, 2400, 5, 9)])
+def test_inverse_update_modes_agree(inverse_update_mode, mode, m, n, k, seed):
+    """Rank-one update per pivot (0) and product form folded in every 32 pivots (1): cold start, a warm
+    start that crashes in more than one batch of basic columns, phase 1 on '=' rows -- both must end at
+    the optimum HiGHS finds, and a warm start from the final basis must need no pivot in either mode."""
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.config1() if (m, n) == (27, 51) else workloads.sparse_lp(m, n, k, seed=seed, stratified=False, frac_upper=0.4)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    assert ref.status == "OPTIMAL"
+    inverse_update_mode(mode)
+    out = solve_lp(lp, "HIP", "primal_simplex", settings())
+    check_vertex(lp, out, ref.obj_val)
+    again = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=out.basis)
+    assert again.iter_count == 0
+    check_vertex(lp, again, ref.obj_val)
+    warm = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=ref.basis)
+    check_vertex(lp, warm, ref.obj_val)
+
+
 def test_warm_start_from_optimal_basis_needs_no_pivot():
     from smart_crossover.solver_caller.solving import solve_lp
     inst = workloads.sparse_lp(120, 400, 4, seed=5, stratified=False, frac_upper=0.4)
