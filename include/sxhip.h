@@ -68,7 +68,9 @@ int sx_ctx_sync(sx_ctx *ctx);
  * column walk in K1/K10: -1 auto [default: decided per matrix from its index clustering on first use],
  * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch),
  * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
- * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]).
+ * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]),
+ * "spx_pricing" (entering variable of sx_simplex_solve*: 0 = Dantzig, largest reduced cost; 1 = Devex
+ * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices).
  * Unknown keys return SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */

@@ -96,6 +96,9 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_graph = value ? 1 : 0;
     } else if (!strcmp(key, "spx_defer")) {
         ctx->opt_spx_defer = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "spx_pricing")) {
+        SX_REQUIRE(value == 0 || value == 1, "spx_pricing must be 0 (Dantzig) or 1 (Devex)");
+        ctx->opt_spx_pricing = static_cast<int>(value);
     } else {
         sx_set_error("unknown option '%s'", key);
         return SX_ERR_INVALID;

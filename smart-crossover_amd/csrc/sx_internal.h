@@ -68,6 +68,7 @@ struct sx_ctx {
     int opt_window = -1;     // LDS operand window of the column walk: -1 auto, 0 off, 1/2/4/8 tiles per load
     int opt_graph = 1;       // replay the CG iteration batch as a hipGraph
     int opt_spx_defer = -1;  // K16 basis inverse: -1 auto, 0 rank-one update per pivot, 1 rank-32 update per batch
+    int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
 };
 
 int sx_reserve(sx_ctx *ctx, size_t bytes);  // ensure ctx->ws holds >= bytes

@@ -11,8 +11,10 @@
 // (m <= 16384 -> 2 GiB) and turns FTRAN / the pivot row / the update into streaming kernels:
 //
 //   price        rc_j = c_j - a_j^T y for all structurals -- the same sequential CSC segment walk
-//                as K1/K10 -- plus the logicals, in one launch; Dantzig rule (Bland's rule after 100
-//                consecutive degenerate pivots); one partial per workgroup
+//                as K1/K10 -- plus the logicals, in one launch; Devex reference weights, brought up to
+//                date with the previous pivot in the same walk (second product per column: rho^T a_j),
+//                or the Dantzig rule ("spx_pricing" 0); Bland's rule after 100 consecutive degenerate
+//                pivots; one partial per workgroup
 //   ftran+ratio  every workgroup reduces the partials to the entering column q (same deterministic
 //                reduction everywhere, no extra launch), then d = Binv a_q: linear combination of the
 //                few columns of Binv that a_q touches.  Each lane owns one basis row and evaluates its
@@ -68,6 +70,9 @@ struct SpxState {
     double rc_q, t, alpha;
     double obj;
     long long n_relaxed; // phase 1: basic logicals still outside their true bounds
+    // Devex: what the next pricing pass needs to bring the reference weights up to date with the last pivot
+    int dvx_on, dvx_p;       // last step changed the basis; variable that left it
+    double dvx_alpha, dvx_wq; // its pivot element; weight of the variable that entered
 };
 
 struct Spx {
@@ -76,6 +81,7 @@ struct Spx {
     int8_t *status;
     uint8_t *relaxed; // logical with phase-1 bounds
     double *lo, *up, *cost, *x;
+    double *w; // Devex reference weights (nullptr: Dantzig pricing)
     // true data of the logicals / costs for the phase switch
     const uint8_t *row_lt;
     const double *c_true;
@@ -101,6 +107,34 @@ struct StageDot {
     const double *__restrict__ vec;
     __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[1]) const { o[0] = v * vec[i]; }
 };
+
+// a_j^T y and a_j^T rho in one walk (Devex: the pivot row entry alpha_rj = rho^T a_j of the last pivot)
+struct StageDot2 {
+    const double *__restrict__ y;
+    const double *__restrict__ rho;
+    __device__ __forceinline__ void operator()(double v, int32_t i, double (&o)[2]) const {
+        o[0] = v * y[i];
+        o[1] = v * rho[i];
+    }
+};
+
+// Devex reference weights (Forrest & Goldfarb 1992, primal form): after a pivot with entering q, leaving p and
+// pivot element alpha, every non-basic j gets w_j = max(w_j, (alpha_rj / alpha)^2 w_q) and p gets
+// max(w_q / alpha^2, 1); the entering variable is then chosen by rc_j^2 / w_j.  The update belongs to the
+// pivot that has just been made but needs alpha_rj for every column -- a second product per column of the
+// walk that prices the next pivot anyway -- so it is done there, from (alpha, w_q, p) left in the state.
+struct DevexLast {
+    int on, p;
+    double inv_alpha2_wq; // w_q / alpha^2
+};
+
+__device__ __forceinline__ double devex_weight(const DevexLast &L, double w, long long j, double alpha_rj) {
+    if (!L.on) return w;
+    if (j == L.p) return fmax(L.inv_alpha2_wq, 1.0);
+    const double cand = alpha_rj * alpha_rj * L.inv_alpha2_wq;
+    // reference framework too old when a weight runs away: start the column over
+    return (cand > 1e12) ? 1.0 : fmax(w, cand);
+}
 
 __device__ __forceinline__ void better(double &s, long long &j, double &rc, double s2, long long j2, double rc2) {
     if (j2 >= 0 && (j < 0 || s2 > s || (s2 == s && j2 < j))) {
@@ -250,37 +284,52 @@ __device__ __forceinline__ void finish_ratio(const Spx &P, const RatioCand &best
 
 // ------------------------------------------------------------------ pricing
 // one launch prices everything: workgroups [0, gP) walk the structural columns, [gP, gridDim) the logicals
+template <bool DEVEX>
 __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__restrict__ tiles, int64_t ntiles,
                                                      const int64_t *__restrict__ colptr,
                                                      const int32_t *__restrict__ rowidx,
                                                      const double *__restrict__ val, double tol, int gP) {
-    if (P.st->done) return;
-    __shared__ sx_walk_lds<1, SPX_CHUNK> lds;
-    const int bland = P.st->bland;
+    const SpxState *st = P.st;
+    if (st->done) return;
+    __shared__ sx_walk_lds<DEVEX ? 2 : 1, SPX_CHUNK> lds;
+    const int bland = st->bland;
+    DevexLast L{0, -1, 0.0};
+    if (DEVEX && st->dvx_on) {
+        L.on = 1;
+        L.p = st->dvx_p;
+        L.inv_alpha2_wq = st->dvx_wq / (st->dvx_alpha * st->dvx_alpha);
+    }
     double s = 0.0, rc = 0.0;
     long long j = -1;
-    if (static_cast<int>(blockIdx.x) >= gP) { // logical columns e_i: rc = cost - y_i
+    // attractiveness: |rc| (Dantzig), rc^2 / w (Devex), 1 for every candidate under Bland's rule
+    auto consider = [&](long long k, double r, double alpha_rk) {
+        const int stk = P.status[k];
+        if (stk == ST_BASIC) return;
+        double sc = score_of(stk, r, P.lo[k], P.up[k], tol, bland);
+        if (DEVEX) {
+            const double w_old = P.w[k], w_new = devex_weight(L, w_old, k, alpha_rk);
+            if (w_new != w_old) P.w[k] = w_new;
+            if (!bland) sc = sc * sc / w_new;
+        }
+        if (sc > 0.0) better(s, j, rc, sc, k, r);
+    };
+    if (static_cast<int>(blockIdx.x) >= gP) { // logical columns e_i: rc = cost - y_i, pivot row entry rho_i
         const int gL = gridDim.x - gP;
         for (int64_t i = static_cast<int64_t>(blockIdx.x - gP) * SX_WG + threadIdx.x; i < P.m;
-             i += static_cast<int64_t>(gL) * SX_WG) {
-            const int64_t k = P.n + i;
-            const double r = P.cost[k] - P.y[i];
-            const double sc = score_of(P.status[k], r, P.lo[k], P.up[k], tol, bland);
-            if (sc > 0.0) better(s, j, rc, sc, k, r);
-        }
+             i += static_cast<int64_t>(gL) * SX_WG)
+            consider(P.n + i, P.cost[P.n + i] - P.y[i], (DEVEX && L.on) ? P.rho[i] : 0.0);
         block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, blockIdx.x);
         return;
     }
     for (int64_t t = blockIdx.x; t < ntiles; t += gP) {
-        double acc[1];
+        double acc[DEVEX ? 2 : 1];
         int64_t col;
         bool valid;
-        sx_segwalk<1, SPX_CHUNK>(tiles, t, colptr, rowidx, val, StageDot{P.y}, lds, col, valid, acc);
-        if (valid) {
-            const double r = P.cost[col] - acc[0];
-            const double sc = score_of(P.status[col], r, P.lo[col], P.up[col], tol, bland);
-            if (sc > 0.0) better(s, j, rc, sc, col, r);
-        }
+        if constexpr (DEVEX)
+            sx_segwalk<2, SPX_CHUNK>(tiles, t, colptr, rowidx, val, StageDot2{P.y, P.rho}, lds, col, valid, acc);
+        else
+            sx_segwalk<1, SPX_CHUNK>(tiles, t, colptr, rowidx, val, StageDot{P.y}, lds, col, valid, acc);
+        if (valid) consider(col, P.cost[col] - acc[0], DEVEX ? acc[1] : 0.0);
     }
     block_best(s, j, rc, P.p_score, P.p_idx, P.p_rc, blockIdx.x);
 }
@@ -499,7 +548,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int pending, int slot)
 // bookkeeping itself -- run by the workgroup that finishes last -- only stores
 struct CommitView {
     int q, dir, flip, r, k;    // entering variable, its direction, bound flip?, pivot row, leaving variable
-    double t, alpha, xq, loq, upq, lok, upk;
+    double t, alpha, xq, loq, upq, lok, upk, wq;
     long long iters, n_relaxed;
     int relaxed_k, row_lt_k;
 };
@@ -518,6 +567,7 @@ __device__ __forceinline__ CommitView commit_view(const Spx &P) {
     v.xq = P.x[v.q];
     v.loq = P.lo[v.q];
     v.upq = P.up[v.q];
+    v.wq = P.w ? P.w[v.q] : 1.0;
     v.k = v.flip ? 0 : P.head[v.r];
     v.lok = v.upk = 0.0;
     v.relaxed_k = v.row_lt_k = 0;
@@ -557,7 +607,11 @@ __device__ __forceinline__ void spx_commit(const Spx &P, const CommitView &v, in
         P.status[q] = ST_BASIC;
         P.head[v.r] = q;
         if (!(fabs(v.alpha) > PIV_TOL)) st->done = 3;
+        st->dvx_p = k;
+        st->dvx_alpha = v.alpha;
+        st->dvx_wq = v.wq;
     }
+    st->dvx_on = v.flip ? 0 : 1;
     st->iters = v.iters + 1;
 }
 
@@ -694,6 +748,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_init(Spx P, const double *__restr
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < N;
          k += static_cast<int64_t>(gridDim.x) * SX_WG) {
         P.relaxed[k] = 0;
+        if (P.w) P.w[k] = 1.0;
         if (k < P.n) {
             const double lk = l[k], uk = u[k];
             P.lo[k] = lk;
@@ -870,6 +925,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_phase2_setup(Spx P) {
     const int64_t N = P.n + P.m;
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < N;
          k += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        if (P.w) P.w[k] = 1.0; // new objective: new reference framework
         if (k < P.n) {
             P.cost[k] = P.c_true[k];
         } else {
@@ -898,6 +954,7 @@ __global__ void k_spx_reset_state(Spx P) {
     st->flip = 0;
     st->q = -1;
     st->r = -1;
+    st->dvx_on = 0;
 }
 
 // outputs in the reference's conventions
@@ -1039,6 +1096,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     // measured (profiles/r01/spx_bench.txt): holding the updates back is as fast as the rank-one update per
     // pivot at 200-1000 rows and 1.3x / 2.2x faster at 2000 / 4000, so "auto" means on
     const bool defer = ctx->opt_spx_defer != 0;
+    const bool devex = ctx->opt_spx_pricing != 0;
 
     DevBufs mem;
     {
@@ -1048,6 +1106,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         if (!session) bytes += sizeof(double) * um * um + 256;
         if (defer) bytes += 2 * sizeof(double) * um * SPX_DEFER + 1024;
         bytes += 32 * (um / SX_WG + 2) + 1024; // ratio candidates, tickets
+        if (devex) bytes += sizeof(double) * uN + 256;
         SX_TRY(mem.reserve(bytes));
     }
     Spx P;
@@ -1061,6 +1120,8 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     SX_TRY(mem.get(static_cast<size_t>(N), &P.up));
     SX_TRY(mem.get(static_cast<size_t>(N), &P.cost));
     SX_TRY(mem.get(static_cast<size_t>(N), &P.x));
+    P.w = nullptr;
+    if (devex) SX_TRY(mem.get(static_cast<size_t>(N), &P.w));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.head));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.y));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.d));
@@ -1219,8 +1280,12 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     const int batch = SPX_DEFER;
     // pivot number k of a batch; with deferred updates it sees k pending pairs and records its own in slot k
     auto enqueue_pivot = [&](int k) {
-        hipLaunchKernelGGL(k_spx_price, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles, A->csc_ptr,
-                           A->csc_idx, A->csc_val, opt_tol, gP);
+        if (devex)
+            hipLaunchKernelGGL(k_spx_price<true>, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles,
+                               A->csc_ptr, A->csc_idx, A->csc_val, opt_tol, gP);
+        else
+            hipLaunchKernelGGL(k_spx_price<false>, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles,
+                               A->csc_ptr, A->csc_idx, A->csc_val, opt_tol, gP);
         hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1, gP + gL,
                            defer ? k : 0, static_cast<const int8_t *>(nullptr), -1);
         hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P, defer ? k : 0, defer ? k : -1);

@@ -182,7 +182,14 @@ def main():
     ap.add_argument("--time-limit", type=int, default=600)
     ap.add_argument("--repeat", type=int, default=1, help="run every case this many times in the process; the first "
                     "run pays library load, context creation and first-touch allocations (reported as cold)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="sx_ctx_set_option on the shared device context, e.g. spx_pricing=1")
     args = ap.parse_args()
+    if args.option:
+        from smart_crossover.hip import default_context
+        for item in args.option:
+            key, value = item.split("=")
+            default_context().set_option(key, int(value))
     cases = ["c3_tnet", "c3_cnet", "c4_cnet"] if args.case == "all" else [args.case]
     first = True
     for case in cases:

@@ -59,24 +59,27 @@ def inverse_update_mode():
     from smart_crossover.hip import default_context
     ctx = default_context()
 
-    def choose(mode):
+    def choose(mode, pricing=1):
         ctx.set_option("spx_defer", mode)
+        ctx.set_option("spx_pricing", pricing)
     yield choose
     ctx.set_option("spx_defer", -1)
+    ctx.set_option("spx_pricing", 1)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,pricing", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("m,n,k,seed", [(27, 51, 2, 2024), (45, 130, 3, 12), (200, 700, 5, 2), (700, 2400, 5, 9)])
-def test_inverse_update_modes_agree(inverse_update_mode, mode, m, n, k, seed):
-    """Rank-one update per pivot (0) and product form folded in every 32 pivots (1): cold start, a warm
-    start that crashes in more than one batch of basic columns, phase 1 on '=' rows -- both must end at
-    the optimum HiGHS finds, and a warm start from the final basis must need no pivot in either mode."""
+def test_inverse_update_modes_agree(inverse_update_mode, mode, pricing, m, n, k, seed):
+    """Rank-one update per pivot (0) and product form folded in every 32 pivots (1), Dantzig (0) and Devex
+    (1) pricing: cold start, a warm start that crashes in more than one batch of basic columns, phase 1 on
+    '=' rows -- all must end at the optimum HiGHS finds, and a warm start from the final basis must need
+    no pivot in any of them."""
     from smart_crossover.solver_caller.solving import solve_lp
     inst = workloads.config1() if (m, n) == (27, 51) else workloads.sparse_lp(m, n, k, seed=seed, stratified=False, frac_upper=0.4)
     lp = general_lp(inst)
     ref = solve_lp(lp, "HGS", "default", settings())
     assert ref.status == "OPTIMAL"
-    inverse_update_mode(mode)
+    inverse_update_mode(mode, pricing)
     out = solve_lp(lp, "HIP", "primal_simplex", settings())
     check_vertex(lp, out, ref.obj_val)
     again = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=out.basis)

@@ -31,11 +31,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="direct launches instead of hipGraph replay (needed under rocprofv3 --kernel-trace, which "
                          "segfaults inside hipGraphLaunch on this image)")
+    ap.add_argument("--pricing", type=int, default=None, help="0 Dantzig, 1 Devex (default: the library's)")
     args = ap.parse_args()
     q = SolverSettings(log_console=0)
     ctx = default_context()
     if args.no_graph:
         ctx.set_option("graph", 0)
+    if args.pricing is not None:
+        ctx.set_option("spx_pricing", args.pricing)
     rows = [int(v) for v in args.rows.split(",")]
     modes = [int(v) for v in args.modes.split(",")]
     warm = workloads.sparse_lp(60, 200, 3, seed=1, stratified=False, frac_upper=0.3)
