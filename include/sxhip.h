@@ -298,7 +298,8 @@ int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const d
  * network_methods/net_manager.py:222,468):
  *     min c^T x   s.t.  (A x)_i = b_i  (row_is_lt[i] == 0)  or  <= b_i  (== 1),   l <= x <= u
  * Bounded revised primal simplex, two phases, explicit dense basis inverse in HBM (m <= 16384, else
- * SX_ERR_UNSUPPORTED), Dantzig pricing with Bland fallback.  vbasis_in[n] / cbasis_in[m] (both or
+ * SX_ERR_UNSUPPORTED) updated once per batch of 32 pivots, Devex pricing with Bland fallback (options
+ * "spx_defer", "spx_pricing" above).  vbasis_in[n] / cbasis_in[m] (both or
  * neither; Gurobi codes 0 basic, -1 lower, -2 upper, -3 free / 0 basic, -1 non-basic) give a warm
  * start; a singular or primal-infeasible warm basis is dropped.  Outputs (device, any may be NULL):
  * x[n], y[m] with reduced cost = c - A^T y, vbasis[n], cbasis[m].  Blocking.  All arrays device. */
