@@ -89,6 +89,27 @@ def test_inverse_update_modes_agree(inverse_update_mode, mode, pricing, m, n, k,
     check_vertex(lp, warm, ref.obj_val)
 
 
+def test_tiny_and_degenerate_shapes():
+    """One row; an empty column (bounded, so it just sits at the cheaper bound); a row nobody touches."""
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.solver_caller.solving import solve_lp
+    one = GeneralLP(sp.csr_matrix(np.array([[1.0, 2.0, 0.0]])), np.array([4.0]), np.array([-1.0, -1.0, 3.0]),
+                    np.zeros(3), np.array([np.inf, np.inf, 5.0]), np.array(["<"]))
+    out = solve_lp(one, "HIP", "default", settings())
+    assert out.status == "OPTIMAL" and out.obj_val == pytest.approx(-4.0)
+    assert out.x == pytest.approx([4.0, 0.0, 0.0])
+    neg = GeneralLP(one.A, one.b, np.array([-1.0, -1.0, -3.0]), one.l, one.u, one.sense)     # empty column wants its upper bound
+    out = solve_lp(neg, "HIP", "default", settings())
+    assert out.status == "OPTIMAL" and out.obj_val == pytest.approx(-19.0) and out.x[2] == pytest.approx(5.0)
+    A = sp.csr_matrix(np.array([[1.0, 1.0], [0.0, 0.0], [1.0, -1.0]]))                      # middle row is empty
+    idle = GeneralLP(A, np.array([2.0, 0.0, 0.0]), np.array([1.0, 2.0]), np.zeros(2), np.full(2, np.inf),
+                     np.array(["=", "=", "="]))
+    out = solve_lp(idle, "HIP", "default", settings())
+    assert out.status == "OPTIMAL" and out.x == pytest.approx([1.0, 1.0]) and out.obj_val == pytest.approx(3.0)
+    bad = GeneralLP(A, np.array([2.0, 1.0, 0.0]), idle.c, idle.l, idle.u, idle.sense)       # 0 = 1 in the empty row
+    assert solve_lp(bad, "HIP", "default", settings()).status == "INFEASIBLE"
+
+
 def test_warm_start_from_optimal_basis_needs_no_pivot():
     from smart_crossover.solver_caller.solving import solve_lp
     inst = workloads.sparse_lp(120, 400, 4, seed=5, stratified=False, frac_upper=0.4)
