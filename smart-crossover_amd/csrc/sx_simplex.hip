@@ -18,12 +18,12 @@
 //   ftran+ratio  every workgroup reduces the partials to the entering column q (same deterministic
 //                reduction everywhere, no extra launch), then d = Binv a_q: linear combination of the
 //                few columns of Binv that a_q touches.  Each lane owns one basis row and evaluates its
-//                entry of the bounded ratio test on the spot; one candidate per workgroup, and the
-//                workgroup that arrives last (ticket) reduces them under a strict total order (smaller
-//                step, then larger pivot -- Bland: smaller variable index --, then row) and decides
-//                between pivot and bound flip of the entering variable
-//   rho+update   rho = row r of the inverse;  x_B -= t*dir*d;  y += (rc_q/d_r) * rho; the last workgroup
-//                to arrive does the basis bookkeeping from values it loaded before the ticket
+//                entry of the bounded ratio test on the spot; one candidate per workgroup goes to memory
+//   rho+update   every workgroup reduces the candidates under a strict total order (smaller step, then
+//                larger pivot -- Bland: smaller variable index --, then row) and decides between pivot
+//                and bound flip of the entering variable, all alike; then rho = row r of the inverse;
+//                x_B -= t*dir*d;  y += (rc_q/d_r) * rho; the last workgroup to arrive (ticket, no fences)
+//                does the basis bookkeeping from values it loaded beforehand
 //   inverse      Binv -= dhat rho^T is the only O(m^2) step (16 m^2 bytes of HBM traffic).  By default it
 //                is not done per pivot: the pairs (dhat_s, rho_s) of a batch of 32 pivots are kept
 //                (product form: Binv_now = Binv - sum_s dhat_s rho_s^T, so FTRAN and the pivot row need
@@ -68,6 +68,7 @@ struct SpxState {
     int done;  // 0 running, 1 no candidate (optimal for the current costs), 2 unbounded, 3 breakdown
     int q, dir, r, flip, bland, degenerate_run;
     double rc_q, t, alpha;
+    double range_q; // up[q] - lo[q] of the entering variable (inf unless it is boxed)
     double obj;
     long long n_relaxed; // phase 1: basic logicals still outside their true bounds
     // Devex: what the next pricing pass needs to bring the reference weights up to date with the last pivot
@@ -230,15 +231,14 @@ __device__ __forceinline__ RatioCand get_cand(const Spx &P, unsigned slot) {
                      P.rt_idx[2 * slot + 1]};
 }
 
-// Every workgroup calls this once it has written its share; true in the one that arrives last, which then
-// sees what all others wrote (release fence before the ticket, acquire fence after it).  A dozen to a few
-// dozen workgroups take a ticket per launch -- unlike the m^2-sized update, where this was tried and lost.
-// With SEES_OTHERS false the fences are left out: for an epilogue that reads nothing the other workgroups
-// wrote and stores to no address they store to (it is then only ordered after their loads).
-template <bool SEES_OTHERS>
+// Every workgroup calls this when it is through with its rows; true in the one that arrives last.  No
+// fences: the epilogue that follows (the basis bookkeeping) reads nothing the other workgroups wrote and
+// stores to no address they store to -- it only has to come after their loads, which the ticket gives.
+// (With fences, ~1 us each, an epilogue could also consume what the others wrote; the ratio test was done
+// that way at first and now rides at the head of the next launch instead.  A dozen to a few dozen
+// workgroups take a ticket per launch -- unlike the m^2-sized update, where this was tried and lost.)
 __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
     __shared__ int is_last;
-    if (SEES_OTHERS) __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = atomicAdd(ticket, 1u);
@@ -246,40 +246,39 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
         if (is_last) atomicExch(ticket, 0u); // ready for the next launch
     }
     __syncthreads();
-    if (SEES_OTHERS && is_last) __threadfence();
     return is_last != 0;
 }
 
-// outcome of the ratio test for entering variable q (single lane): pivot row or bound flip, step, Bland switch
-// `range` = up[q] - lo[q] (inf unless the entering variable is boxed) and the run of degenerate steps so far
-// come in as values loaded early in the launch: after the ticket only stores remain, no load round trips.
-__device__ __forceinline__ void finish_ratio(const Spx &P, const RatioCand &best, double range, int degenerate_run) {
-    SpxState *st = P.st;
+// outcome of the ratio test for entering variable q: pivot row or bound flip, step
+// `range` = up[q] - lo[q] (inf unless the entering variable is boxed)
+struct RatioOutcome {
+    int unbounded, flip, r;
+    double t, alpha;
+};
+
+__device__ __forceinline__ RatioOutcome ratio_outcome(const RatioCand &best, double range) {
+    RatioOutcome o;
     const double best_t = (best.row >= 0) ? best.t : INFINITY;
-    if (!(best_t < INFINITY) && !(range < INFINITY)) {
-        st->done = 2; // unbounded ray
-        return;
+    o.unbounded = (!(best_t < INFINITY) && !(range < INFINITY)) ? 1 : 0; // ray
+    o.flip = (range <= best_t) ? 1 : 0;
+    o.t = o.flip ? range : best_t;
+    o.r = o.flip ? -1 : best.row;
+    o.alpha = o.flip ? 1.0 : best.dval;
+    return o;
+}
+
+// The candidates the preceding k_spx_ftran launch left (one per workgroup, same grid), reduced to the
+// winner in every lane of every workgroup: same inputs, strict total order -> same answer everywhere.
+__device__ __forceinline__ RatioCand reduce_candidates(const Spx &P, int bland, RatioCand *lds /* [SX_WG / 64 + 1] */) {
+    RatioCand best{INFINITY, 0.0, 0.0, -1, 0};
+    for (unsigned p = threadIdx.x; p < gridDim.x; p += SX_WG) {
+        const RatioCand c = get_cand(P, p);
+        if (cand_better(c, best, bland)) best = c;
     }
-    double t;
-    if (range <= best_t) {
-        t = range;
-        st->flip = 1;
-        st->r = -1;
-        st->alpha = 1.0;
-    } else {
-        t = best_t;
-        st->flip = 0;
-        st->r = best.row;
-        st->alpha = best.dval;
-    }
-    st->t = t;
-    if (t <= 1e-12) {
-        st->degenerate_run = degenerate_run + 1;
-        if (degenerate_run + 1 > BLAND_AFTER) st->bland = 1;
-    } else {
-        st->degenerate_run = 0;
-        st->bland = 0;
-    }
+    best = block_best_cand(best, bland, lds);
+    if (threadIdx.x == 0) lds[SX_WG / 64] = best;
+    __syncthreads();
+    return lds[SX_WG / 64];
 }
 
 // ------------------------------------------------------------------ pricing
@@ -338,22 +337,20 @@ __global__ __launch_bounds__(SX_WG) void k_spx_price(Spx P, const int64_t *__res
 // In the pivot loop (q_override < 0) every workgroup first repeats the selection of the entering column
 // from the pricing partials -- a deterministic reduction, so all arrive at the same q without another
 // launch -- and workgroup 0 records it in the state; the ratio test follows in the same launch.
-// With q_override >= 0 (installing a warm basis) column q_override is transformed and given the row, among
-// those still held by a logical, where it has the largest entry (crash_cb: the warm basis' row codes,
-// rows whose logical it keeps basic are taken only if nothing else works; crash_slot: where a deferred
-// update is recorded, or -1).
+// With q_override >= 0 (installing a warm basis) column q_override is transformed and the candidates are
+// for the row, among those still held by a logical, where it has the largest entry (crash_cb: the warm
+// basis' row codes, rows whose logical it keeps basic are taken only if nothing else works).
 __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__restrict__ colptr,
                                                      const int32_t *__restrict__ rowidx,
                                                      const double *__restrict__ val, int q_override, int nslots,
-                                                     int pending, const int8_t *__restrict__ crash_cb,
-                                                     int crash_slot) {
+                                                     int pending, const int8_t *__restrict__ crash_cb) {
     __shared__ double sh_s[SX_WG / 64], sh_rc[SX_WG / 64];
     __shared__ long long sh_j[SX_WG / 64];
     __shared__ double coef[SPX_DEFER];
     __shared__ RatioCand sh_c[SX_WG / 64];
     int64_t q = q_override;
     const bool fuse = q_override < 0; // pivot loop: the ratio test rides along
-    int dirq = 1, bland = 0, degenerate_run = 0;
+    int dirq = 1, bland = 0;
     RatioCand best{INFINITY, 0.0, 0.0, -1, 0};
     // A pivot is a chain of dependent memory round trips, about a microsecond each, and little else; so
     // everything that does not depend on the entering column is requested here, before it is known: this
@@ -372,7 +369,6 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
         SpxState *st = P.st;
         if (st->done) return;
         bland = st->bland;
-        degenerate_run = st->degenerate_run;
         double s = 0.0, rc = 0.0;
         long long j = -1;
         for (int k = threadIdx.x; k < nslots; k += SX_WG) better(s, j, rc, P.p_score[k], P.p_idx[k], P.p_rc[k]);
@@ -411,6 +407,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
                 st->q = static_cast<int>(j);
                 st->rc_q = rc;
                 st->dir = dirq;
+                st->range_q = range;
             }
         }
         if (none) return;
@@ -459,46 +456,11 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
             best = RatioCand{-fabs(acc) * pref, 0.0, acc, static_cast<int>(i), hk}; // smallest t = largest weight
         }
     }
-    if (!fuse) {
-        best = block_best_cand(best, 0, sh_c);
-        if (threadIdx.x == 0) put_cand(P, blockIdx.x, best);
-        if (!last_block_arrives<true>(P.tickets)) return;
-        best = RatioCand{INFINITY, 0.0, 0.0, -1, 0};
-        for (unsigned p = threadIdx.x; p < gridDim.x; p += SX_WG) {
-            const RatioCand c = get_cand(P, p);
-            if (cand_better(c, best, 0)) best = c;
-        }
-        best = block_best_cand(best, 0, sh_c);
-        if (threadIdx.x == 0) { // the column takes row best.row; flip == 1 makes k_spx_rho skip a column without one
-            SpxState *st = P.st;
-            const int br = best.row;
-            st->done = 0;
-            st->q = qs;
-            st->r = br;
-            st->flip = (br < 0) ? 1 : 0;
-            st->alpha = (br >= 0) ? best.dval : 1.0;
-            if (crash_slot >= 0) P.er[crash_slot] = br;
-            if (br >= 0) {
-                P.status[best.hk] = ST_LOWER;
-                P.x[best.hk] = 0.0;
-                P.status[qs] = ST_BASIC;
-                P.head[br] = qs;
-            }
-        }
-        return;
-    }
-    // ratio test without a launch of its own: one candidate per workgroup, and the workgroup that arrives
-    // last reduces them (strict total order -> the result does not depend on which one that is)
-    best = block_best_cand(best, bland, sh_c);
+    // One candidate per workgroup goes to memory; the launch that follows (k_spx_rho_update, k_spx_rho)
+    // starts by reducing them -- every workgroup the same way, under a strict total order -- so the ratio
+    // test needs neither a launch nor a device-wide rendezvous of its own.
+    best = block_best_cand(best, fuse ? bland : 0, sh_c);
     if (threadIdx.x == 0) put_cand(P, blockIdx.x, best);
-    if (!last_block_arrives<true>(P.tickets)) return;
-    best = RatioCand{INFINITY, 0.0, 0.0, -1, 0};
-    for (unsigned p = threadIdx.x; p < gridDim.x; p += SX_WG) {
-        const RatioCand c = get_cand(P, p);
-        if (cand_better(c, best, bland)) best = c;
-    }
-    best = block_best_cand(best, bland, sh_c);
-    if (threadIdx.x == 0) finish_ratio(P, best, range, degenerate_run);
 }
 
 // rho = row r of Binv (strided gather), before Binv changes
@@ -529,12 +491,32 @@ __device__ __forceinline__ void record_update(const Spx &P, int64_t r, int64_t i
     P.E[i + slot * P.m] = (i == r) ? (alpha - 1.0) * inv : P.d[i] * inv;
 }
 
-__global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int pending, int slot) {
+// Installing warm-basis column q: the row it takes is the best candidate k_spx_ftran left (every workgroup
+// reduces them the same way); workgroup 0 does the bookkeeping, the rest as above.  A column without a
+// usable row is skipped (flip = 1 in the state, slot marked empty).
+__global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int q, int pending, int slot) {
     __shared__ double w[SPX_DEFER];
-    const SpxState *st = P.st;
-    if (st->done || st->flip) return;
-    const int64_t m = P.m, r = st->r;
-    const double alpha = st->alpha;
+    __shared__ RatioCand sh_c[SX_WG / 64 + 1];
+    const RatioCand pick = reduce_candidates(P, 0, sh_c);
+    const int br = pick.row;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SpxState *st = P.st;
+        st->done = 0;
+        st->q = q;
+        st->r = br;
+        st->flip = (br < 0) ? 1 : 0;
+        st->alpha = (br >= 0) ? pick.dval : 1.0;
+        if (slot >= 0) P.er[slot] = br;
+        if (br >= 0) { // nobody reads head / status in this launch
+            P.status[pick.hk] = ST_LOWER;
+            P.x[pick.hk] = 0.0;
+            P.status[q] = ST_BASIC;
+            P.head[br] = q;
+        }
+    }
+    if (br < 0) return;
+    const int64_t m = P.m, r = br;
+    const double alpha = pick.dval;
     rho_weights(P, r, pending, w);
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < m;
          k += static_cast<int64_t>(gridDim.x) * SX_WG) {
@@ -550,18 +532,19 @@ struct CommitView {
     int q, dir, flip, r, k;    // entering variable, its direction, bound flip?, pivot row, leaving variable
     double t, alpha, xq, loq, upq, lok, upk, wq;
     long long iters, n_relaxed;
-    int relaxed_k, row_lt_k;
+    int relaxed_k, row_lt_k, degenerate_run;
 };
 
-__device__ __forceinline__ CommitView commit_view(const Spx &P) {
+__device__ __forceinline__ CommitView commit_view(const Spx &P, int q, int dir, const RatioOutcome &o) {
     const SpxState *st = P.st;
     CommitView v;
-    v.q = st->q;
-    v.dir = st->dir;
-    v.flip = st->flip;
-    v.r = st->r;
-    v.t = st->t;
-    v.alpha = st->alpha;
+    v.q = q;
+    v.dir = dir;
+    v.flip = o.flip;
+    v.r = o.r;
+    v.t = o.t;
+    v.alpha = o.alpha;
+    v.degenerate_run = st->degenerate_run;
     v.iters = st->iters;
     v.n_relaxed = st->n_relaxed;
     v.xq = P.x[v.q];
@@ -584,6 +567,18 @@ __device__ __forceinline__ CommitView commit_view(const Spx &P) {
 __device__ __forceinline__ void spx_commit(const Spx &P, const CommitView &v, int slot) {
     SpxState *st = P.st;
     if (slot >= 0) P.er[slot] = v.flip ? -1 : v.r; // does the slot hold an update for k_spx_fold?
+    // outcome of the ratio test, for the host, the update per pivot ("spx_defer" 0) and the next launches
+    st->flip = v.flip;
+    st->t = v.t;
+    st->r = v.r;
+    st->alpha = v.alpha;
+    if (v.t <= 1e-12) {
+        st->degenerate_run = v.degenerate_run + 1;
+        if (v.degenerate_run + 1 > BLAND_AFTER) st->bland = 1;
+    } else {
+        st->degenerate_run = 0;
+        st->bland = 0;
+    }
     const int q = v.q;
     if (v.flip) {
         P.status[q] = (v.dir > 0) ? ST_UPPER : ST_LOWER;
@@ -620,6 +615,7 @@ __device__ __forceinline__ void spx_commit(const Spx &P, const CommitView &v, in
 // One row per lane (host: grid = m / SX_WG), loads ordered by what they depend on, as in k_spx_ftran.
 __global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, int slot) {
     __shared__ double w[SPX_DEFER];
+    __shared__ RatioCand sh_c[SX_WG / 64 + 1];
     const SpxState *st = P.st;
     const int64_t m = P.m;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
@@ -636,14 +632,27 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, in
         if (slot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) P.er[slot] = -1; // nothing recorded in this slot
         return;
     }
-    const double step = st->t * st->dir;
-    const bool pivot = !st->flip;
-    const double alpha = st->alpha;
-    const double mult = pivot ? st->rc_q / alpha : 0.0;
-    const int64_t r = st->r;
+    // ratio test: the candidates of k_spx_ftran's workgroups, reduced here by every workgroup alike.  The
+    // state is not written before the bookkeeping at the end (a workgroup that starts late must read the
+    // same `bland` and `done` as the others).
+    const int q = st->q, dir = st->dir;
+    const double rc_q = st->rc_q;
+    const RatioOutcome out = ratio_outcome(reduce_candidates(P, st->bland, sh_c), st->range_q);
+    if (out.unbounded) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            P.st->done = 2; // a late workgroup then leaves through the check above: same effect
+            if (slot >= 0) P.er[slot] = -1;
+        }
+        return;
+    }
+    const double step = out.t * dir;
+    const bool pivot = !out.flip;
+    const double alpha = out.alpha;
+    const double mult = pivot ? rc_q / alpha : 0.0;
+    const int64_t r = out.r;
     // second round trip: needs the pivot row / this row's variable
     CommitView view;
-    if (threadIdx.x == 0) view = commit_view(P);
+    if (threadIdx.x == 0) view = commit_view(P, q, dir, out);
     const double xk = have ? P.x[hk] : 0.0;
     double rho_i = (pivot && have) ? P.Binv[r + i * m] : 0.0;
     if (pivot && pending > 0) {
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, in
             }
         }
     }
-    if (last_block_arrives<false>(P.tickets + 1) && threadIdx.x == 0) spx_commit(P, view, slot);
+    if (last_block_arrives(P.tickets) && threadIdx.x == 0) spx_commit(P, view, slot);
 }
 
 // Deferred form of the update below: the `cnt` recorded pairs of a batch go into the inverse in one pass,
@@ -1256,8 +1265,9 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         for (int64_t j = 0; j < n; ++j) {
             if (vb[static_cast<size_t>(j)] != ST_BASIC) continue;
             hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val,
-                               static_cast<int>(j), 0, defer ? slot : 0, cbasis_in, defer ? slot : -1);
-            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P, defer ? slot : 0, defer ? slot : -1);
+                               static_cast<int>(j), 0, defer ? slot : 0, cbasis_in);
+            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P, static_cast<int>(j), defer ? slot : 0,
+                               defer ? slot : -1);
             if (!defer) {
                 hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
             } else if (++slot == SPX_DEFER) {
@@ -1287,7 +1297,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             hipLaunchKernelGGL(k_spx_price<false>, dim3(gP + gL), dim3(SX_WG), 0, s, P, A->csc_tiles, A->n_csc_tiles,
                                A->csc_ptr, A->csc_idx, A->csc_val, opt_tol, gP);
         hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val, -1, gP + gL,
-                           defer ? k : 0, static_cast<const int8_t *>(nullptr), -1);
+                           defer ? k : 0, static_cast<const int8_t *>(nullptr));
         hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P, defer ? k : 0, defer ? k : -1);
         if (!defer) hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
     };
