@@ -258,19 +258,53 @@ static int upload_padded(sx_ctx *ctx, const T *host, int64_t count, T **dev_out)
     return SX_OK;
 }
 
-static int check_ptr(const int64_t *ptr, int64_t nseg, int64_t nnz, const char *what) {
+// Validation of a layout's offsets and inner indices.  The O(1) checks are done on the host before
+// anything is uploaded; the O(n) / O(nnz) scans run on the device copies (first offending position by
+// atomicMin) and are read back before any kernel uses the arrays as addresses.
+constexpr unsigned long long SX_NO_BAD = ~0ull;
+
+__global__ __launch_bounds__(256) void k_check_layout(const int64_t *__restrict__ ptr, int64_t nseg,
+                                                      const int32_t *__restrict__ idx, int64_t nnz, int64_t bound,
+                                                      unsigned long long *__restrict__ bad /* [0] ptr, [1] idx */) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long bp = SX_NO_BAD, bi = SX_NO_BAD;
+    for (int64_t s = t0; s < nseg; s += stride)
+        if (ptr[s + 1] < ptr[s] && static_cast<unsigned long long>(s) < bp) bp = static_cast<unsigned long long>(s);
+    for (int64_t k = t0; k < nnz; k += stride) {
+        const int32_t v = idx[k];
+        if ((v < 0 || v >= bound) && static_cast<unsigned long long>(k) < bi) bi = static_cast<unsigned long long>(k);
+    }
+    if (bp != SX_NO_BAD) atomicMin(bad, bp);
+    if (bi != SX_NO_BAD) atomicMin(bad + 1, bi);
+}
+
+static int check_ends(const int64_t *ptr, int64_t nseg, int64_t nnz, const char *what) {
     SX_REQUIRE(ptr[0] == 0, "%s[0] must be 0", what);
-    for (int64_t s = 0; s < nseg; ++s)
-        SX_REQUIRE(ptr[s + 1] >= ptr[s], "%s is not non-decreasing at %lld", what, (long long)s);
     SX_REQUIRE(ptr[nseg] == nnz, "%s[last] = %lld but nnz = %lld", what, (long long)ptr[nseg],
                (long long)nnz);
     return SX_OK;
 }
 
-static int check_idx(const int32_t *idx, int64_t nnz, int64_t bound, const char *what) {
-    for (int64_t k = 0; k < nnz; ++k)
-        SX_REQUIRE(idx[k] >= 0 && idx[k] < bound, "%s[%lld] = %d out of range [0,%lld)", what,
-                   (long long)k, idx[k], (long long)bound);
+// host_* are the caller's arrays (for the message), dev_* their uploaded copies
+static int check_layout_dev(sx_ctx *ctx, const int64_t *dev_ptr, int64_t nseg, const int32_t *dev_idx,
+                            const int32_t *host_idx, int64_t nnz, int64_t bound, const char *ptr_name,
+                            const char *idx_name) {
+    SX_TRY(sx_reserve(ctx, 2 * sizeof(unsigned long long)));
+    unsigned long long *bad = static_cast<unsigned long long *>(ctx->ws);
+    SX_HIP(hipMemsetAsync(bad, 0xff, 2 * sizeof(unsigned long long), ctx->stream));
+    const int64_t work = nseg > nnz ? nseg : nnz;
+    int64_t grid = (work + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_check_layout, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, dev_ptr, nseg,
+                       dev_idx, nnz, bound, bad);
+    unsigned long long host_bad[2] = {SX_NO_BAD, SX_NO_BAD};
+    SX_HIP(hipMemcpyAsync(host_bad, bad, sizeof(host_bad), hipMemcpyDeviceToHost, ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    SX_REQUIRE(host_bad[0] == SX_NO_BAD, "%s is not non-decreasing at %lld", ptr_name, (long long)host_bad[0]);
+    SX_REQUIRE(host_bad[1] == SX_NO_BAD, "%s[%lld] = %d out of range [0,%lld)", idx_name, (long long)host_bad[1],
+               host_idx[host_bad[1]], (long long)bound);
     return SX_OK;
 }
 
@@ -285,13 +319,11 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
     SX_REQUIRE(m < INT32_MAX && n < INT32_MAX, "dimension exceeds int32 inner-index range");
     SX_REQUIRE(csr_rowptr != nullptr, "csr_rowptr is NULL");
     SX_REQUIRE(nnz == 0 || (csr_col && csr_val), "csr_col/csr_val is NULL");
-    SX_TRY(check_ptr(csr_rowptr, m, nnz, "csr_rowptr"));
-    SX_TRY(check_idx(csr_col, nnz, n, "csr_col"));
+    SX_TRY(check_ends(csr_rowptr, m, nnz, "csr_rowptr"));
     const bool have_csc = csc_colptr != nullptr;
     if (have_csc) {
         SX_REQUIRE(nnz == 0 || (csc_row && csc_val), "csc_row/csc_val is NULL");
-        SX_TRY(check_ptr(csc_colptr, n, nnz, "csc_colptr"));
-        SX_TRY(check_idx(csc_row, nnz, m, "csc_row"));
+        SX_TRY(check_ends(csc_colptr, n, nnz, "csc_colptr"));
     }
     sx_matrix *A = new (std::nothrow) sx_matrix();
     if (!A) {
@@ -305,11 +337,13 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
     int rc = SX_OK;
     if ((rc = upload_padded(ctx, csr_rowptr, m + 1, &A->csr_ptr)) == SX_OK &&
         (rc = upload_padded(ctx, csr_col, nnz, &A->csr_idx)) == SX_OK &&
-        (rc = upload_padded(ctx, csr_val, nnz, &A->csr_val)) == SX_OK) {
+        (rc = upload_padded(ctx, csr_val, nnz, &A->csr_val)) == SX_OK &&
+        (rc = check_layout_dev(ctx, A->csr_ptr, m, A->csr_idx, csr_col, nnz, n, "csr_rowptr", "csr_col")) == SX_OK) {
         if (have_csc) {
             if ((rc = upload_padded(ctx, csc_colptr, n + 1, &A->csc_ptr)) == SX_OK &&
-                (rc = upload_padded(ctx, csc_row, nnz, &A->csc_idx)) == SX_OK)
-                rc = upload_padded(ctx, csc_val, nnz, &A->csc_val);
+                (rc = upload_padded(ctx, csc_row, nnz, &A->csc_idx)) == SX_OK &&
+                (rc = upload_padded(ctx, csc_val, nnz, &A->csc_val)) == SX_OK)
+                rc = check_layout_dev(ctx, A->csc_ptr, n, A->csc_idx, csc_row, nnz, m, "csc_colptr", "csc_row");
         } else {
             // stable transposition on the device (sx_transpose.hip): per-column entries in row-major walk order
             rc = sx_transpose_dev(ctx, m, n, nnz, A->csr_ptr, A->csr_idx, A->csr_val, &A->csc_ptr, &A->csc_idx,
@@ -341,8 +375,7 @@ SX_API int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nn
     SX_REQUIRE(ptr != nullptr, "ptr is NULL");
     SX_REQUIRE(nnz == 0 || (idx && val), "idx/val is NULL");
     const int64_t nseg = is_csc ? n : m, bound = is_csc ? m : n;
-    SX_TRY(check_ptr(ptr, nseg, nnz, is_csc ? "colptr" : "rowptr"));
-    SX_TRY(check_idx(idx, nnz, bound, is_csc ? "row index" : "column index"));
+    SX_TRY(check_ends(ptr, nseg, nnz, is_csc ? "colptr" : "rowptr"));
     sx_matrix *A = new (std::nothrow) sx_matrix();
     if (!A) {
         sx_set_error("out of host memory");
@@ -362,10 +395,9 @@ SX_API int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nn
             (rc = upload_padded(ctx, idx, nnz, &A->csr_idx)) == SX_OK &&
             (rc = upload_padded(ctx, val, nnz, &A->csr_val));
     }
-    if (rc == SX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        sx_set_error("stream sync failed after matrix upload");
-        rc = SX_ERR_HIP;
-    }
+    if (rc == SX_OK) // synchronises: the uploads are complete afterwards
+        rc = check_layout_dev(ctx, is_csc ? A->csc_ptr : A->csr_ptr, nseg, is_csc ? A->csc_idx : A->csr_idx, idx, nnz,
+                              bound, is_csc ? "colptr" : "rowptr", is_csc ? "row index" : "column index");
     if (rc == SX_OK)
         rc = is_csc ? sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles)
                     : sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles);

@@ -241,6 +241,45 @@ def test_host_pointer_entry_points(ctx):
         sxl.check(lib.sx_score_rows(ctx.handle, None, p(inst.x), p(inst.b), p(inst.y), 1e-3, p(s_p), p(flag)))
 
 
+def test_matrix_index_arrays_are_validated(ctx):
+    """Offsets and inner indices are checked (on the device copies) before any kernel uses them as
+    addresses: the error names the first offending position."""
+    from smart_crossover.hip import lib as sxl
+    lib = sxl.load()
+    A = ragged_matrix(5)
+    m, n = A.shape
+    rowptr, col, val = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data
+
+    def create(rp, ci, single=False):
+        h = C.c_void_p()
+        if single:
+            return lib.sx_matrix_create_single(ctx.handle, m, n, A.nnz, 0, rp.ctypes.data, ci.ctypes.data, val.ctypes.data,
+                                               C.byref(h))
+        return lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rp.ctypes.data, ci.ctypes.data, val.ctypes.data,
+                                    None, None, None, C.byref(h))
+
+    for single in (False, True):
+        bad_col = col.copy()
+        bad_col[A.nnz // 2] = n                                   # one past the last column
+        bad_col[A.nnz - 1] = -1
+        with pytest.raises(ValueError, match=rf"\[{A.nnz // 2}\] = {n} out of range"):
+            sxl.check(create(rowptr, bad_col, single))
+        bad_ptr = rowptr.copy()
+        k = int(np.flatnonzero(np.diff(rowptr) > 0)[3])            # a non-empty row in the middle
+        bad_ptr[k + 1] = bad_ptr[k] - 1 if bad_ptr[k] > 0 else bad_ptr[k + 2] + 1
+        with pytest.raises(ValueError, match="not non-decreasing"):
+            sxl.check(create(bad_ptr, col, single))
+        short = rowptr.copy()
+        short[-1] -= 1
+        with pytest.raises(ValueError, match="but nnz"):
+            sxl.check(create(short, col, single))
+    # and a valid one still goes through afterwards
+    h = C.c_void_p()
+    sxl.check(lib.sx_matrix_create(ctx.handle, m, n, A.nnz, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data,
+                                   None, None, None, C.byref(h)))
+    sxl.check(lib.sx_matrix_destroy(h))
+
+
 def test_matrix_roundtrip_and_library_csc(ctx):
     """Library-side CSR->CSC (when the caller passes no CSC) equals the walk order."""
     from smart_crossover.hip import lib as sxl
