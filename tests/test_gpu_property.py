@@ -146,17 +146,31 @@ def test_sub_problem_compaction_on_random_codes(ctx, seed, m, n, frac):
     assert bits_equal(got.data, A.data[kept])
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=120, deadline=None, derandomize=True,
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(seed=st.integers(0, 2 ** 31 - 1), m=st.integers(1, 24), n=st.integers(1, 40),
-       kind=st.sampled_from(["feasible", "degenerate", "free", "maybe_infeasible", "maybe_unbounded"]))
-def test_device_simplex_agrees_with_highs_on_random_small_lps(seed, m, n, kind):
-    """K16 against scipy's HiGHS on small LPs of every flavour: same status, same optimal value, and a
+       kind=st.sampled_from(["feasible", "degenerate", "free", "maybe_infeasible", "maybe_unbounded"]),
+       defer=st.sampled_from([0, 1]), pricing=st.sampled_from([0, 1]))
+def test_device_simplex_agrees_with_highs_on_random_small_lps(seed, m, n, kind, defer, pricing):
+    """K16 against scipy's HiGHS on small LPs of every flavour, under every combination of its two options
+    (inverse updated per pivot / per batch, Dantzig / Devex): same status, same optimal value, and a
     returned basis that certifies the vertex (primal and dual feasible, m basic variables)."""
     from scipy.optimize import linprog
     from smart_crossover.formats import GeneralLP
+    from smart_crossover.hip import default_context
     from smart_crossover.solver_caller.caller import SolverSettings
     from smart_crossover.solver_caller.solving import solve_lp
+    dev = default_context()
+    dev.set_option("spx_defer", defer)
+    dev.set_option("spx_pricing", pricing)
+    try:
+        _simplex_case(seed, m, n, kind, linprog, GeneralLP, SolverSettings, solve_lp)
+    finally:
+        dev.set_option("spx_defer", -1)
+        dev.set_option("spx_pricing", 1)
+
+
+def _simplex_case(seed, m, n, kind, linprog, GeneralLP, SolverSettings, solve_lp):
     rng = np.random.default_rng(seed)
     A = sp.random(m, n, density=min(1.0, 3.0 / max(n, 1) + 0.15), random_state=seed % (2 ** 31), format="csr")
     A.data = np.round(rng.uniform(-3, 3, A.nnz) * 2) / 2                       # halves: plenty of ties
