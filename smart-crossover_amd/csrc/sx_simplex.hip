@@ -1316,6 +1316,10 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     auto build_graph = [&]() {
         graph_tried = true;
         if (!ctx->opt_graph) return;
+        // rocprofv3 --kernel-trace (ROCm 7.2) segfaults inside hipGraphLaunch after some thousands of
+        // replays of this graph; with three launches per pivot direct launches are as fast
+        // (profiles/r01/spx_bench.txt), so a profiled run simply does not replay
+        if (getenv("ROCP_TOOL_LIBRARIES") != nullptr) return;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             enqueue_batch();
             if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
