@@ -1309,7 +1309,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     // replayed (pivots are launch-bound for small m); direct launches are the fallback.  Capturing and
     // instantiating costs milliseconds, more than a short warm-started re-solve takes altogether, so the
     // graph is only built once a solve has gone through GRAPH_AFTER pivots by direct launches.
-    const int64_t GRAPH_AFTER = 256;
+    const int64_t GRAPH_AFTER = 4096; // with 3 launches per pivot replay only insures against a slow host
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool graph_tried = false;
