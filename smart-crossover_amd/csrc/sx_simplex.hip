@@ -49,7 +49,10 @@
 #include "sx_internal.h"
 #include "sx_segwalk.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
@@ -1102,6 +1105,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     }
     if (max_iter <= 0) max_iter = 50 * (m + n) + 1000;
     hipStream_t s = ctx->stream;
+    const auto t_enter = std::chrono::steady_clock::now();
     // measured (profiles/r01/spx_bench.txt): holding the updates back is as fast as the rank-one update per
     // pivot at 200-1000 rows and 1.3x / 2.2x faster at 2000 / 4000, so "auto" means on
     const bool defer = ctx->opt_spx_defer != 0;
@@ -1258,7 +1262,14 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         }
     }
     if (session) session->valid = false; // until this solve has left a basis behind
+    const bool trace = getenv("SX_SPX_TRACE") != nullptr; // stderr: where the wall time of a solve goes
+    auto since_enter = [&]() {
+        (void)hipStreamSynchronize(s);
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    };
+    const double t_setup_ms = trace ? since_enter() : 0.0;
     if (!reused) cold_start(1);
+    double t_crash_ms = 0.0;
     if (vbasis_in && !reused) {
         hipLaunchKernelGGL(k_spx_apply_vbasis, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in);
         int slot = 0;
@@ -1276,6 +1287,11 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             }
         }
         if (defer && slot > 0) fold(slot);
+        if (trace) {
+            const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+            fprintf(stderr, "[sx_simplex] warm basis: launches enqueued by %.2f ms\n", enq);
+            t_crash_ms = since_enter();
+        }
         hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
         refresh(true);
         SX_TRY(measure());
@@ -1283,6 +1299,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         if (!warm) cold_start(1); // singular or infeasible warm basis: start from the logicals
     }
     SX_HIP(hipGetLastError());
+    const double t_start_ms = trace ? since_enter() : 0.0;
 
     // ---- phases
     SpxState host;
@@ -1395,6 +1412,15 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     hipLaunchKernelGGL(k_spx_export, dim3(gN), dim3(SX_WG), 0, s, P, x_out, y_out, vbasis_out, cbasis_out);
     SX_HIP(hipGetLastError());
     SX_HIP(hipStreamSynchronize(s));
+    if (trace) {
+        const double t_all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+        fprintf(stderr,
+                "[sx_simplex] m=%lld n=%lld start=%s: set-up %.2f ms, basis %.2f ms (columns installed by %.2f), "
+                "phases %.2f ms, %lld pivots (%lld in phase 1), status %d\n",
+                (long long)m, (long long)n, reused ? "kept inverse" : (vbasis_in ? (warm ? "crash" : "crash dropped") : "cold"),
+                t_setup_ms, t_start_ms - t_setup_ms, t_crash_ms > 0 ? t_crash_ms - t_setup_ms : 0.0, t_all - t_start_ms,
+                (long long)host.iters, (long long)phase1_iters, status);
+    }
     result->status = status;
     result->iters = host.iters;
     result->phase1_iters = phase1_iters;
