@@ -65,6 +65,7 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
     if (ctx->t_made)
         for (int i = 0; i < 8; ++i) {
             (void)hipEventDestroy(ctx->t0[i]);

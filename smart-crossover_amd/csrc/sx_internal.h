@@ -54,6 +54,10 @@ struct sx_ctx {
     size_t ws_bytes = 0;
     void *ws2 = nullptr; // second block (sx_reserve2)
     size_t ws2_bytes = 0;
+    // dense basis inverse of the last simplex session that was destroyed: the next session with the same
+    // row count takes it over instead of allocating (a crossover opens one session per call)
+    double *spare_binv = nullptr;
+    int64_t spare_binv_m = 0;
     // timers
     hipEvent_t t0[8];
     hipEvent_t t1[8];

@@ -1072,7 +1072,13 @@ SX_API int sx_simplex_session_create(sx_ctx *ctx, sx_simplex_session **out) {
 SX_API int sx_simplex_session_destroy(sx_simplex_session *session) {
     if (!session) return SX_OK;
     sx_device_guard guard(session->ctx->device);
-    if (session->Binv) (void)hipFree(session->Binv);
+    if (session->Binv) { // parked in the context for the next session of the same size (one spare at most)
+        sx_ctx *ctx = session->ctx;
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
+        ctx->spare_binv = session->Binv;
+        ctx->spare_binv_m = session->m;
+    }
     delete session;
     return SX_OK;
 }
@@ -1146,8 +1152,14 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             session->Binv = nullptr;
             session->valid = false;
             session->m = m;
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&session->Binv),
-                             sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(m) + 1)));
+            if (ctx->spare_binv && ctx->spare_binv_m == m) {
+                session->Binv = ctx->spare_binv;
+                ctx->spare_binv = nullptr;
+                ctx->spare_binv_m = 0;
+            } else {
+                SX_HIP(hipMalloc(reinterpret_cast<void **>(&session->Binv),
+                                 sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(m) + 1)));
+            }
         }
         P.Binv = session->Binv;
     } else {
