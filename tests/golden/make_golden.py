@@ -12,7 +12,7 @@ pinned numpy 1.21 / scipy 1.7 and this image (``np.Inf``; ``cg(tol=)`` ->
 ``cg(rtol=, atol=0)``, i.e. the same relative stopping rule).
 
 Outputs (all data, no source):  g1_lp_afiro.npz, g2_lp_small.npz,
-g3_mcf_small.npz, g4_ot_small.npz, g5_cg_schedule.json, digests.json.
+g3_mcf_small.npz, g4_ot_small.npz, g5_cg_schedule.json, g6_control_flow.json, digests.json.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -312,6 +312,106 @@ def cg_cases():
     return cases
 
 
+# ------------------------------------------------------------------ control flow of run_perturb_algorithm (G6)
+def canned_backend(inst, script, barrier_obj, log):
+    """Stand-in for ``solve_lp`` at the module seam of lp_methods/algorithms.py (the reference calls the
+    name ``solve_lp`` it imported, :38,50,69).  It performs no optimisation: every answer is a fixed function
+    of its arguments, so that the reference and the build can be driven through the same branches.
+      call 0 (the initial barrier solve)  -> (inst.x, inst.y, barrier_obj), OPTIMAL
+      re-solve k (method 'barrier')       -> status script[k]; x, y = the warm start it was handed;
+                                             vbasis = 0 where x > 1e-3 else -1; cbasis = -1
+      final solve ('primal_simplex')      -> x, y = the warm start it was handed, OPTIMAL
+    tests/test_gpu_control_flow.py implements the same function for the build."""
+    state = {"resolves": 0}
+
+    def solve_lp(lp, solver="GRB", method="default", settings=None, warm_start_basis=None, warm_start_solution=None):
+        rec = dict(method=method, n=int(lp.c.size), m=int(lp.b.size), solver=solver,
+                   presolve=settings.presolve, crossover=settings.crossover, barrierTol=settings.barrierTol,
+                   optimalityTol=settings.optimalityTol, log_file=settings.log_file,
+                   has_ws_solution=warm_start_solution is not None, has_ws_basis=warm_start_basis is not None)
+        call = len(log)
+        if call == 0:
+            out = Output(x=inst.x.copy(), y=inst.y.copy(), obj_val=barrier_obj, status="OPTIMAL",
+                         runtime=datetime.timedelta(0), iter_count=0, bar_iter_count=7)
+        elif method == "barrier":
+            status = script[state["resolves"]]
+            state["resolves"] += 1
+            xs, ys = warm_start_solution
+            rec["c_sub"] = np.asarray(lp.c).tolist()
+            rec["n_eq_rows"] = int(np.count_nonzero(np.asarray(lp.sense) == "="))
+            out = Output(x=np.asarray(xs).copy(), y=np.asarray(ys).copy(), obj_val=float(lp.c @ xs), status=status,
+                         runtime=datetime.timedelta(0), iter_count=0,
+                         basis=Basis(np.where(np.asarray(xs) > 1e-3, 0, -1), np.full(lp.b.size, -1)))
+        else:
+            xs, ys = warm_start_solution
+            rec["ws_x"] = np.asarray(xs).tolist()
+            rec["ws_vbasis"] = np.asarray(warm_start_basis.vbasis).astype(int).tolist()
+            rec["ws_cbasis"] = np.asarray(warm_start_basis.cbasis).astype(int).tolist()
+            out = Output(x=np.asarray(xs).copy(), y=np.asarray(ys).copy(), obj_val=float(lp.c @ xs), status="OPTIMAL",
+                         runtime=datetime.timedelta(0), iter_count=11,
+                         basis=Basis(np.asarray(warm_start_basis.vbasis), np.asarray(warm_start_basis.cbasis)))
+        rec["returned_status"] = out.status
+        log.append((rec, out))
+        return out
+
+    return solve_lp
+
+
+def _exact_nullspace_projection(A, v, A_f=None):
+    """Harness stand-in for the reference's Gurobi QP (apply_projector_qp, algorithms.py:240-265) on the
+    small golden LPs: the exact orthogonal projection by dense least squares."""
+    Ad = np.asarray(sp.csr_matrix(A).todense())
+    if A_f is not None:
+        raise NotImplementedError("golden LPs have no free variables")
+    z, *_ = np.linalg.lstsq(Ad @ Ad.T, Ad @ v, rcond=None)
+    return v - Ad.T @ z
+
+
+def control_flow_case(name, inst, script, early):
+    lp = GeneralLP(inst.A.copy(), inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
+    # gamma in force at the re-solve that succeeds
+    g, gd = 1e-3, 1e-3
+    for status in script:
+        if status in ("INFEASIBLE", "UNBOUNDED"):
+            g, gd = g * 1e-5, gd * 1e-5 ** 2
+    mgr = quiet(ref_alg.get_perturb_problem, lp, inst.x, inst.y, g, gd, False)
+    exact = float(lp.c @ mgr.get_orix(mgr.get_subx(inst.x)))
+    barrier_obj = exact if early else exact * 1.5 + 1.0
+    log, gammas = [], []
+    real_solve, real_qp, real_gpp = ref_alg.solve_lp, ref_alg.apply_projector_qp, ref_alg.get_perturb_problem
+
+    def rec_gpp(lp_, x, y, gamma, gamma_dual, is_feas):
+        m_ = real_gpp(lp_, x, y, gamma, gamma_dual, is_feas)
+        gammas.append(dict(gamma=gamma, gamma_dual=gamma_dual, is_feas=bool(is_feas),
+                           n_fix_low=int(m_.var_info["fix_low"].size), n_fix_up=int(m_.var_info["fix_up"].size),
+                           n_fixed_rows=int(m_.fixed_constraints.size)))
+        return m_
+
+    ref_alg.solve_lp = canned_backend(inst, script, barrier_obj, log)
+    ref_alg.apply_projector_qp = _exact_nullspace_projection
+    ref_alg.get_perturb_problem = rec_gpp
+    buf = io.StringIO()
+    try:
+        with redirect_stdout(buf):
+            result = ref_alg.run_perturb_algorithm(lp, solver="CANNED", barrierTol=1e-7, optimalityTol=1e-5, log_file="")
+    finally:
+        ref_alg.solve_lp, ref_alg.apply_projector_qp, ref_alg.get_perturb_problem = real_solve, real_qp, real_gpp
+    returned_by = [i for i, (_, o) in enumerate(log) if o is result]
+    return dict(name=name, script=list(script), early=bool(early), barrier_obj=barrier_obj,
+                calls=[r for r, _ in log], gammas=gammas, printed=buf.getvalue().splitlines(),
+                returned_by_call=returned_by[0], result_status=result.status, result_x_len=int(np.asarray(result.x).size))
+
+
+def control_flow_cases():
+    c1 = workloads.config1()
+    g2 = workloads.sparse_lp(300, 1500, 6, seed=12, stratified=False, frac_upper=0.3)
+    return [control_flow_case("afiro_early_return", c1, ["OPTIMAL"], True),
+            control_flow_case("afiro_gap_then_simplex", c1, ["OPTIMAL"], False),
+            control_flow_case("afiro_infeasible_once_then_simplex", c1, ["INFEASIBLE", "OPTIMAL"], False),
+            control_flow_case("small_unbounded_twice_early_return", g2, ["UNBOUNDED", "UNBOUNDED", "OPTIMAL"], True),
+            control_flow_case("small_infeasible_unbounded_then_simplex", g2, ["INFEASIBLE", "UNBOUNDED", "OPTIMAL"], False)]
+
+
 # ------------------------------------------------------------------ digests on larger, regenerated inputs
 def digest_cases():
     d = {}
@@ -354,6 +454,8 @@ def main():
         json.dump(cg_cases(), f, indent=1)
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(digest_cases(), f, indent=1)
+    with open(os.path.join(HERE, "g6_control_flow.json"), "w") as f:
+        json.dump(control_flow_cases(), f, indent=1)
     for name in sorted(os.listdir(HERE)):
         print(f"{name:28s} {os.path.getsize(os.path.join(HERE, name)):9d} B")
     print("g1: fixed", g1["fix"].size, "rows", g1["fixed_rows"].size, "cg iters", int(g1["cg_iters"]), "info", int(g1["cg_info"]))
