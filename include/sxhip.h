@@ -70,7 +70,11 @@ int sx_ctx_sync(sx_ctx *ctx);
  * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
  * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]),
  * "spx_pricing" (entering variable of sx_simplex_solve*: 0 = Dantzig, largest reduced cost; 1 = Devex
- * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices).
+ * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices),
+ * "rowblock" (column-blocked copy of the rows for the row walk of sx_score_rows and the projector CG:
+ * -1 auto [default: built on first use for matrices of >= 4M entries when at least half of them fall into
+ * column blocks dense enough for an LDS window], 0 off, 1 whenever the matrix admits it; results are
+ * bit-identical either way -- a matrix with a row whose column indices descend somewhere keeps the plain walk).
  * Unknown keys return SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
@@ -117,6 +121,14 @@ int sx_matrix_arrays(const sx_matrix *A, const int64_t **csr_rowptr, const int32
                      const double **csc_val);
 /* download CSR arrays of a device matrix (rowptr[m+1], col[nnz], val[nnz]) */
 int sx_matrix_download_csr(const sx_matrix *A, int64_t *rowptr, int32_t *col, double *val);
+/* Column-blocked row layout of A under the context's "rowblock" option (built now if it is due):
+ * info[0..5] = super-tiles, cells, chunks, entries incl. gaps, entries in windowed cells, uint16 slots per
+ * cell of the row-start table; all zero when the matrix uses the plain walk.  The second call copies the
+ * layout's arrays to the host (NULL = skip): st[info0] (24-byte records), chunks[info2] (32-byte records),
+ * rowstart[info1 * info5], idx / val [info3 + 8] -- for tests and tools (csrc/sx_rowblock.h). */
+int sx_matrix_rowblock_info(sx_ctx *ctx, const sx_matrix *A, int64_t *info);
+int sx_matrix_rowblock_download(sx_ctx *ctx, const sx_matrix *A, void *st, void *chunks, uint16_t *rowstart,
+                                int32_t *idx, double *val);
 
 /* ------------------------------------------------------------------ K1: column scoring
  * replaces GeneralLP.get_dual_slack (formats.py:70-72) and the two np.where tests of

@@ -13,6 +13,7 @@
 // and the stopping rule (||r|| < tol*||b||, tested before each iteration; legacy immediate exit when
 // ||b|| <= tol) are those of the reference's pinned scipy.
 #include "sx_internal.h"
+#include "sx_rowblock.h"
 #include "sx_segwalk.h"
 #include "sx_window.h"
 
@@ -332,6 +333,29 @@ inline int grid_for(const sx_ctx *ctx, int64_t ntiles) {
     return static_cast<int>(g < 1 ? 1 : g);
 }
 
+// degenerate shapes: with no rows Y is empty and the projector is the identity, proj = xa .* c; with no
+// columns the only directions are slack columns, which Y = diag(xs) pins to zero wherever xs != 0
+__global__ __launch_bounds__(1024) void k_cg_no_rows(int64_t n, const double *__restrict__ xa,
+                                                     const double *__restrict__ c, double *__restrict__ proj_cols,
+                                                     double *__restrict__ sumsq_out) {
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 1024) {
+        const double v = xa[j] * c[j];
+        if (proj_cols) proj_cols[j] = v;
+        acc = acc + v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = part[0];
+        for (int w = 1; w < 16; ++w) t += part[w];
+        *sumsq_out = t;
+    }
+}
+
 } // namespace
 
 SX_API int sx_projector_dev(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
@@ -350,7 +374,22 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     SX_REQUIRE(maxiter >= 0 && tol >= 0, "bad tol/maxiter");
     const int64_t m = A->m, n = A->n;
     memset(result, 0, sizeof(*result));
-    if (m == 0 || n == 0) return SX_OK;
+    if (m == 0 || n == 0) {
+        // the reference's apply_projector on an empty Y returns v unchanged (algorithms.py:183-187)
+        result->converged = 1;
+        if (n == 0) {
+            if (proj_rows && m > 0) SX_HIP(hipMemsetAsync(proj_rows, 0, sizeof(double) * static_cast<size_t>(m), ctx->stream));
+            return SX_OK;
+        }
+        SX_TRY(sx_reserve(ctx, 256));
+        double *sumsq = static_cast<double *>(ctx->ws);
+        hipLaunchKernelGGL(k_cg_no_rows, dim3(1), dim3(1024), 0, ctx->stream, n, xa, c, proj_cols, sumsq);
+        double host_sumsq = 0.0;
+        SX_HIP(hipMemcpyAsync(&host_sumsq, sumsq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SX_HIP(hipStreamSynchronize(ctx->stream));
+        result->proj_norm = sqrt(host_sumsq);
+        return SX_OK;
+    }
 
     const int swzT = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
     const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64) ? 1 : 0;
@@ -391,12 +430,22 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
             hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A->csc_tiles, A->n_csc_tiles, swzT, A->csc_ptr,
                                A->csc_idx, A->csc_val, in, scale, out);
     };
+    // row pass q = A w (+ xs^2 .* p), partials of p.q (or q.q) in ppq: over the column-blocked copy of the rows
+    // when the matrix has one (sx_rowblock.h), else the plain walk; nA = number of partials either leaves
+    const sx_rowblock *rb = nullptr;
+    SX_TRY(sx_rowblock_get(ctx, A, &rb));
+    int nA = gA;
+    auto launch_a = [&](const double *vec, const double *pvec, double *out) -> int {
+        if (rb) return sx_rb_cg_a(ctx, rb, n, st, vec, xs, pvec, out, ppq, CG_GRID, &nA);
+        hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA, A->csr_ptr,
+                           A->csr_idx, A->csr_val, vec, xs, pvec, out, ppq);
+        return SX_OK;
+    };
     SX_HIP(hipMemsetAsync(st, 0, sizeof(CgState), s));
     // b = A (xa^2 .* c) -> r ; rho0 = b.b
     hipLaunchKernelGGL(k_cg_scale_c, dim3(gv), dim3(SX_WG), 0, s, n, xa, c, w);
-    hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
-                       A->csr_ptr, A->csr_idx, A->csr_val, w, xs, static_cast<const double *>(nullptr), r, ppq);
-    int n_rho0 = gA;
+    SX_TRY(launch_a(w, nullptr, r));
+    int n_rho0 = nA;
     if (cs) { // slack columns carry a cost: b += xs^2 .* cs, rho0 recomputed from the completed b
         hipLaunchKernelGGL(k_cg_slack_cost, dim3(gv), dim3(SX_WG), 0, s, m, xs, cs, r, ppq);
         n_rho0 = gv;
@@ -415,9 +464,8 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     if (!trivial && !(bnrm < tol * bnrm)) { // scipy tests ||r|| < atol before the first iteration too
         auto enqueue_iteration = [&](int par) {
             launch_at(p, xa, w);
-            hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A->csr_tiles, A->n_csr_tiles, swzA,
-                               A->csr_ptr, A->csr_idx, A->csr_val, w, xs, p, q, ppq);
-            hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, gA, p, q, z, r, prr);
+            (void)launch_a(w, p, q);
+            hipLaunchKernelGGL(k_cg_update_zr, dim3(gv), dim3(SX_WG), 0, s, st, par, m, ppq, nA, p, q, z, r, prr);
             hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(SX_WG), 0, s, st, par, m, prr, gv, r, p);
         };
         // the loop is launch-bound on cache-resident problems (four ~4 us kernels per iteration): a

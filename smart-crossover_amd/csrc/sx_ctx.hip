@@ -1,5 +1,6 @@
 // Context, memory plumbing, stopwatch and matrix residency of libsxhip.so.
 #include "sx_internal.h"
+#include "sx_rowblock.h"
 
 #include <algorithm>
 
@@ -97,6 +98,9 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_graph = value ? 1 : 0;
     } else if (!strcmp(key, "spx_defer")) {
         ctx->opt_spx_defer = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "rowblock")) {
+        SX_REQUIRE(value >= -1 && value <= 1, "rowblock must be -1 (auto), 0 (off) or 1 (whenever possible)");
+        ctx->opt_rowblock = static_cast<int>(value);
     } else if (!strcmp(key, "spx_pricing")) {
         SX_REQUIRE(value == 0 || value == 1, "spx_pricing must be 0 (Dantzig) or 1 (Devex)");
         ctx->opt_spx_pricing = static_cast<int>(value);
@@ -418,6 +422,7 @@ SX_API int sx_matrix_destroy(sx_matrix *A) {
                      A->csc_val, A->csr_tiles, A->csc_tiles, A->csc_win_lo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    sx_rowblock_free(A->rb);
     delete A;
     return SX_OK;
 }

@@ -72,6 +72,7 @@ struct sx_ctx {
     int opt_window = -1;     // LDS operand window of the column walk: -1 auto, 0 off, 1/2/4/8 tiles per load
     int opt_graph = 1;       // replay the CG iteration batch as a hipGraph
     int opt_spx_defer = -1;  // K16 basis inverse: -1 auto, 0 rank-one update per pivot, 1 rank-32 update per batch
+    int opt_rowblock = -1;   // column-blocked row layout of the row walk: -1 auto, 0 off, 1 whenever possible
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
 };
 
@@ -96,6 +97,9 @@ struct sx_matrix {
     mutable int32_t *csc_win_lo = nullptr;
     mutable int csc_win_tried = 0;
     mutable int csc_win_useful = 0; // verdict of the auto rule
+    // optional column-blocked copy of the rows (sx_rowblock.h), built on first use of a row walk
+    mutable struct sx_rowblock *rb = nullptr;
+    mutable int rb_tried = 0; // 1: the automatic rule has spoken, 2: so has a forced build
 };
 
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
@@ -111,6 +115,11 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
                    int64_t *ntiles_out);
 // exclusive scan of in[0..n) into out[0..n] (out[n] = total); uses ctx->ws (sx_compact.hip)
 int sx_scan_exclusive(sx_ctx *ctx, const int64_t *in, int64_t n, int64_t *out);
+
+// stable LSD radix sort of (uint64 key, int32 payload) pairs on the low `nbytes` bytes (sx_sort.hip)
+int64_t sx_sort_blocks(int64_t n);
+int sx_sort_pairs(sx_ctx *ctx, int64_t n, uint64_t *const img[2], int32_t *const idx[2], int64_t *hist, int64_t *offs,
+                  int nbytes, int *cur_out);
 
 // RAII guard: make the context's device current for the duration of a call.
 struct sx_device_guard {

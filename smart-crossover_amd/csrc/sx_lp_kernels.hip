@@ -3,6 +3,7 @@
 // and DESIGN.md for layout / roofline notes.  Built with -ffp-contract=off: every product and
 // every sum below is a separately rounded binary64 operation.
 #include "sx_internal.h"
+#include "sx_rowblock.h"
 #include "sx_segwalk.h"
 #include "sx_window.h"
 
@@ -548,6 +549,11 @@ SX_API int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, c
     SX_REQUIRE(x && b, "x or b is NULL");
     SX_REQUIRE(!flag || y, "flag requested but y is NULL");
     if (A->m == 0) return SX_OK;
+    {   // column-blocked copy of the rows, when the matrix has (or is due) one: same bits, fewer L2 requests
+        const sx_rowblock *rb = nullptr;
+        SX_TRY(sx_rowblock_get(ctx, A, &rb));
+        if (rb) return sx_rb_score_rows(ctx, rb, A->n, x, b, y, gamma_dual, s_p, flag);
+    }
     const unsigned grid = walk_grid(ctx, A->n_csr_tiles);
 #define SX_LAUNCH_K2(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_rows<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,           \

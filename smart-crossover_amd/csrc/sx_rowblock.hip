@@ -1,0 +1,334 @@
+// Row walk over the column-blocked row layout (sx_rowblock.h): K2 score_rows
+// (reference formats.py:74-76 + lp_methods/algorithms.py:106) and the CSR product of the projector CG
+// (lp_methods/algorithms.py:183-187).  Same sums, same roundings as the plain walk of sx_segwalk.h;
+// built with -ffp-contract=off.
+//
+// One workgroup of RB_R lanes owns a super-tile (one row per lane) and steps through its chunks.  Step k:
+//   issue    if chunk k+1 opens a new cell: its row starts and its x window (registers); then the entries of
+//            chunk k+1 (registers) -- the youngest loads, which the waits of this step leave in flight
+//   stage    rounded products of chunk k -> LDS; the operand comes from the LDS window of the cell, or from
+//            global memory for a direct cell
+//   consume  lane t adds the products of row t that lie in this chunk, left to right
+//   publish  window of chunk k+1 -> LDS (behind the stage barrier: every gather of chunk k is done)
+// Loads are raw buffer loads: descriptor in scalar registers, lanes past the end read zeros, no clamps.
+// The entry stream is read once and marked non-temporal so that it does not evict the x windows, which
+// neighbouring super-tiles re-read, from the XCD's L2.
+// MI355X, config 5 (1e6 x 1e7, 8e7 entries): 0.36 ms against 0.61 ms for the plain walk
+// (profiles/r02/rb_bench_*.txt), L1<->L2 requests 8.45e7 -> ~2e7.
+#include "sx_internal.h"
+#include "sx_rowblock.h"
+#include "sx_segwalk.h"
+
+namespace {
+
+constexpr int RB_TW = RB_R;                     // lanes per workgroup
+constexpr int RB_NQ = RB_CHUNK / (RB_TW * 4);   // 16-byte index loads per lane and chunk
+constexpr int RB_NW = RB_CWIN / (RB_TW * 2);    // 16-byte window pieces per lane
+constexpr int RB_NT = 2;                        // cache policy of the entry stream: non-temporal
+constexpr int RB_MINW = 6;                      // waves per SIMD the register budget allows (3 workgroups / CU)
+static_assert(RB_CHUNK % (RB_TW * 4) == 0 && RB_CWIN % (RB_TW * 2) == 0, "chunk / window vs workgroup");
+
+struct RbEntries { // the entries one lane stages of one chunk
+    sx_v4i i[RB_NQ];
+    sx_v2d v01[RB_NQ], v23[RB_NQ];
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, static_cast<int>(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ void rb_load(RbEntries &E, const sx_rb_chunk &c, const int32_t *__restrict__ idx,
+                                        const double *__restrict__ val) {
+    const uint32_t ne4 = static_cast<uint32_t>((c.ne + 3) & ~3);
+    const __amdgpu_buffer_rsrc_t ri = rb_rsrc(idx + c.e0, ne4 * 4u), rv = rb_rsrc(val + c.e0, ne4 * 8u);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < RB_NQ; ++q) {
+        E.i[q] = __builtin_amdgcn_raw_buffer_load_b128(ri, tid * 16, q * RB_TW * 16, RB_NT);
+        E.v01[q] = __builtin_bit_cast(sx_v2d, __builtin_amdgcn_raw_buffer_load_b128(rv, tid * 32, q * RB_TW * 32, RB_NT));
+        E.v23[q] = __builtin_bit_cast(sx_v2d, __builtin_amdgcn_raw_buffer_load_b128(rv, tid * 32 + 16, q * RB_TW * 32, RB_NT));
+    }
+}
+
+// lanes past the chunk hold zeros (index 0, value 0.0): their products land in slots no row segment covers
+__device__ __forceinline__ void rb_stage(const RbEntries &E, const sx_rb_chunk &c, const double *win,
+                                         const double *__restrict__ x, double *prod) {
+    const int tid = threadIdx.x;
+    if (c.col0 != RB_NO_WINDOW) {
+        const double *w0 = win - c.col0; // only dereferenced inside [win, win + RB_CWIN)
+#pragma unroll
+        for (int q = 0; q < RB_NQ; ++q) {
+            const int off = q * RB_TW * 4 + tid * 4;
+            const bool live = off < c.ne; // the gap behind the cell holds (col0, 0.0): in range as well
+            const int i0 = live ? E.i[q].x : c.col0, i1 = live ? E.i[q].y : c.col0;
+            const int i2 = live ? E.i[q].z : c.col0, i3 = live ? E.i[q].w : c.col0;
+            double2 *dst = reinterpret_cast<double2 *>(prod + off);
+            dst[0] = make_double2(E.v01[q].x * w0[i0], E.v01[q].y * w0[i1]);
+            dst[1] = make_double2(E.v23[q].x * w0[i2], E.v23[q].y * w0[i3]);
+        }
+    } else {
+        double xv[RB_NQ][4];
+#pragma unroll
+        for (int q = 0; q < RB_NQ; ++q) {
+            xv[q][0] = x[E.i[q].x];
+            xv[q][1] = x[E.i[q].y];
+            xv[q][2] = x[E.i[q].z];
+            xv[q][3] = x[E.i[q].w];
+        }
+#pragma unroll
+        for (int q = 0; q < RB_NQ; ++q) {
+            const int off = q * RB_TW * 4 + tid * 4;
+            double2 *dst = reinterpret_cast<double2 *>(prod + off);
+            dst[0] = make_double2(E.v01[q].x * xv[q][0], E.v01[q].y * xv[q][1]);
+            dst[1] = make_double2(E.v23[q].x * xv[q][2], E.v23[q].y * xv[q][3]);
+        }
+    }
+}
+
+// one row per lane: the batched loop for long segments, then at most two rounds of four with the adds
+// selected by the remaining count (prod[] has 8 slack slots behind the chunk, so the reads need no clamp)
+__device__ __forceinline__ void rb_consume(double &acc, int rs0, int rs1, int base, int ne, const double *prod) {
+    const int k0 = rs0 > base ? rs0 : base;
+    const int k1 = rs1 < base + ne ? rs1 : base + ne;
+    int o = k0 - base;
+    int left = k1 - k0;
+    double a = acc;
+    for (; left >= 8; left -= 8, o += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = prod[o + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a = a + t[q];
+    }
+    if (__builtin_amdgcn_ballot_w64(left > 0)) {
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = prod[o + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double s2 = a + t[q];
+                a = (q < left) ? s2 : a;
+            }
+            o += 4;
+            left -= 4;
+            if (round == 0 && !__builtin_amdgcn_ballot_w64(left > 0)) break;
+        }
+    }
+    acc = a;
+}
+
+// chunk records of the super-tile are read through LDS, RB_TAB at a time (+ the look-ahead of the last one)
+constexpr int RB_TAB = 64;
+constexpr int RB_TABN = RB_TAB + 2;
+
+struct RbLds {
+    double win[RB_CWIN];
+    double prod[RB_CHUNK + 8];
+    int tab[RB_TABN * 8];
+};
+
+__device__ __forceinline__ sx_rb_chunk rb_record(const int *tab, int slot) {
+    const int *p = tab + slot * 8;
+    sx_rb_chunk c;
+    const int lo = __builtin_amdgcn_readfirstlane(p[0]), hi = __builtin_amdgcn_readfirstlane(p[1]);
+    c.e0 = (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+    c.ne = __builtin_amdgcn_readfirstlane(p[2]);
+    c.col0 = __builtin_amdgcn_readfirstlane(p[3]);
+    c.cell = __builtin_amdgcn_readfirstlane(p[4]);
+    c.base = __builtin_amdgcn_readfirstlane(p[5]);
+    c.fresh = __builtin_amdgcn_readfirstlane(p[6]);
+    c.pad_ = 0;
+    return c;
+}
+
+struct RbLayout {
+    const sx_rb_supertile *__restrict__ st;
+    const sx_rb_chunk *__restrict__ chunks;
+    const uint16_t *__restrict__ rowstart;
+    const int32_t *__restrict__ idx;
+    const double *__restrict__ val;
+    int64_t nst;
+};
+
+// sum of row S.row0 + tid over the super-tile (0 for lanes beyond its rows); all lanes of the workgroup call it
+__device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_rb_supertile &S, const double *__restrict__ x,
+                                                   int64_t ncols, RbLds &lds) {
+    const int tid = threadIdx.x;
+    const int *ck = reinterpret_cast<const int *>(L.chunks + S.chunk0);
+    const int n = S.nchunks;
+    double acc = 0.0;
+    if (n <= 0) return acc;
+    int g = 0;
+    auto load_tab = [&]() {
+        for (int i = tid; i < RB_TABN * 8; i += RB_TW) {
+            int rec = g + i / 8;
+            rec = rec < n ? rec : n - 1;
+            lds.tab[i] = ck[static_cast<int64_t>(rec) * 8 + (i & 7)];
+        }
+    };
+    auto load_rs = [&](int (&rs)[2], const sx_rb_chunk &c) {
+        const __amdgpu_buffer_rsrc_t rr = rb_rsrc(L.rowstart + static_cast<int64_t>(c.cell) * RB_RS_STRIDE, RB_RS_STRIDE * 2u);
+        const int k0 = tid < S.nrows ? tid : S.nrows, k1 = tid + 1 < S.nrows ? tid + 1 : S.nrows;
+        rs[0] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k0 * 2, 0, 0));
+        rs[1] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k1 * 2, 0, 0));
+    };
+    auto load_win = [&](sx_v2d (&wreg)[RB_NW], const sx_rb_chunk &c) {
+        const int64_t room = ncols - c.col0;
+        const __amdgpu_buffer_rsrc_t rw = rb_rsrc(x + c.col0, static_cast<uint32_t>(room < RB_CWIN ? room : RB_CWIN) * 8u);
+#pragma unroll
+        for (int w = 0; w < RB_NW; ++w)
+            wreg[w] = __builtin_bit_cast(sx_v2d, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16, w * RB_TW * 16, 0));
+    };
+    auto store_win = [&](const sx_v2d (&wreg)[RB_NW]) {
+#pragma unroll
+        for (int w = 0; w < RB_NW; ++w) *reinterpret_cast<sx_v2d *>(lds.win + w * RB_TW * 2 + tid * 2) = wreg[w];
+    };
+    int rs[2], rs_next[2];
+    RbEntries E[2];
+    sx_v2d wreg[RB_NW];
+    __syncthreads(); // the previous super-tile of a grid-stride caller is done with the LDS
+    load_tab();
+    __syncthreads();
+    sx_rb_chunk c = rb_record(lds.tab, 0);
+    load_rs(rs, c);
+    if (c.col0 != RB_NO_WINDOW) load_win(wreg, c);
+    rb_load(E[0], c, L.idx, L.val);
+    if (c.col0 != RB_NO_WINDOW) store_win(wreg);
+    __syncthreads();
+    auto step = [&](RbEntries &Ecur, RbEntries &Enext, int k) {
+        const bool has_next = k + 1 < n;
+        const sx_rb_chunk cn = rb_record(lds.tab, (has_next ? k + 1 : k) - g);
+        const bool open = has_next && cn.fresh;
+        const bool new_win = open && cn.col0 != RB_NO_WINDOW;
+        if (open) load_rs(rs_next, cn);
+        if (new_win) load_win(wreg, cn);
+        if (has_next) rb_load(Enext, cn, L.idx, L.val);
+        rb_stage(Ecur, c, lds.win, x, lds.prod);
+        __syncthreads();
+        rb_consume(acc, rs[0], rs[1], c.base, c.ne, lds.prod);
+        if (new_win) store_win(wreg);
+        if (open) {
+            rs[0] = rs_next[0];
+            rs[1] = rs_next[1];
+        }
+        if (has_next && k + 1 == g + RB_TAB) { // next group of records
+            __syncthreads();
+            g += RB_TAB;
+            load_tab();
+        }
+        __syncthreads();
+        c = cn;
+    };
+    for (int k = 0; k < n; k += 2) {
+        step(E[0], E[1], k);
+        if (k + 1 < n) step(E[1], E[0], k + 1);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------- K2
+__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_score_rows(RbLayout L, int swizzle, const double *__restrict__ x,
+                                                                  int64_t ncols, const double *__restrict__ b,
+                                                                  const double *__restrict__ y, double gamma_dual,
+                                                                  double *__restrict__ s_p, uint8_t *__restrict__ flag) {
+    __shared__ RbLds lds;
+    const int64_t tile = sx_tile_of_block(blockIdx.x, L.nst, swizzle);
+    if (tile >= L.nst) return;
+    const sx_rb_supertile S = L.st[tile];
+    const double sum = rb_supertile_sum(L, S, x, ncols, lds);
+    if (static_cast<int>(threadIdx.x) < S.nrows) {
+        const int64_t row = S.row0 + threadIdx.x;
+        const double sp = b[row] - sum;
+        if (s_p) s_p[row] = sp;
+        if (flag) flag[row] = (sp < (gamma_dual * (-y[row]))) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------- CG, CSR pass
+// q[i] = (A w)[i] + xs[i]^2 * p[i];  partial[block] = sum p[i]*q[i]; with p == nullptr: q = A w,
+// partial = sum q[i]^2 -- k_cg_a of sx_cg.hip over the layout.
+struct RbCgState { // leading fields of CgState (sx_cg.hip): only `done` is read here
+    double rho[2];
+    double atol;
+    double sumsq;
+    long long iters;
+    int done;
+    int converged;
+};
+
+__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swizzle, const RbCgState *st,
+                                                            const double *__restrict__ w, int64_t ncols,
+                                                            const double *__restrict__ xs, const double *__restrict__ p,
+                                                            double *__restrict__ q, double *__restrict__ partial) {
+    if (st->done) return;
+    __shared__ RbLds lds;
+    __shared__ double wave_sum[RB_TW / 64];
+    int64_t t = blockIdx.x, t_end = L.nst, t_step = gridDim.x;
+    if (swizzle) { // gridDim.x is a multiple of 8: XCD k walks the contiguous super-tiles [k*per, (k+1)*per)
+        const int64_t per = (L.nst + 7) >> 3;
+        t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        t_end = ((blockIdx.x & 7) + 1) * per;
+        if (t_end > L.nst) t_end = L.nst;
+        t_step = gridDim.x >> 3;
+    }
+    double dot = 0.0;
+    for (; t < t_end; t += t_step) {
+        const sx_rb_supertile S = L.st[t];
+        double qi = rb_supertile_sum(L, S, w, ncols, lds);
+        if (static_cast<int>(threadIdx.x) < S.nrows) {
+            const int64_t row = S.row0 + threadIdx.x;
+            if (p) {
+                const double s = xs[row], pi = p[row];
+                qi = qi + (s * s) * pi;
+                dot += pi * qi;
+            } else {
+                dot += qi * qi;
+            }
+            q[row] = qi;
+        }
+    }
+    // fixed-order block sum
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = wave_sum[0];
+#pragma unroll
+        for (int k = 1; k < RB_TW / 64; ++k) tot += wave_sum[k];
+        partial[blockIdx.x] = tot;
+    }
+}
+
+inline RbLayout layout_of(const sx_rowblock *rb) {
+    return RbLayout{rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->nst};
+}
+
+} // namespace
+
+int sx_rb_score_rows(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const double *x, const double *b,
+                     const double *y, double gamma_dual, double *s_p, uint8_t *flag) {
+    if (rb->nst == 0) return SX_OK;
+    const int swz = ctx->opt_xcd_swizzle;
+    const unsigned grid = swz ? static_cast<unsigned>(((rb->nst + 7) >> 3) << 3) : static_cast<unsigned>(rb->nst);
+    hipLaunchKernelGGL(k_rb_score_rows, dim3(grid), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, x, ncols, b, y,
+                       gamma_dual, s_p, flag);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+int sx_rb_cg_a(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const void *cg_state, const double *w,
+               const double *xs, const double *p, double *q, double *partial, int max_parts, int *nparts) {
+    int64_t g = rb->nst < max_parts ? rb->nst : max_parts;
+    const int swz = (ctx->opt_xcd_swizzle && rb->nst >= 64) ? 1 : 0;
+    if (swz) g &= ~static_cast<int64_t>(7);
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_rb_cg_a, dim3(static_cast<unsigned>(g)), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz,
+                       static_cast<const RbCgState *>(cg_state), w, ncols, xs, p, q, partial);
+    SX_HIP(hipGetLastError());
+    *nparts = static_cast<int>(g);
+    return SX_OK;
+}

@@ -121,13 +121,38 @@ inline unsigned grid1d(int64_t n, int64_t cap = 8192) {
 
 } // namespace
 
+// Stable LSD radix sort of n (64-bit key, int32 payload) pairs on the `nbytes` low-order bytes of the key
+// (internal: the transposition and the row-block layout builder sort integer keys with it).  img[0] / idx[0]
+// hold the input, img[1] / idx[1] are the second buffers, hist / offs hold 256 * nblocks + 1 counters each
+// (nblocks = sx_sort_blocks(n)); *cur_out says which buffer pair holds the result.
+int64_t sx_sort_blocks(int64_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+
+int sx_sort_pairs(sx_ctx *ctx, int64_t n, uint64_t *const img[2], int32_t *const idx[2], int64_t *hist, int64_t *offs,
+                  int nbytes, int *cur_out) {
+    const int64_t nblocks = sx_sort_blocks(n);
+    hipStream_t s = ctx->stream;
+    int cur = 0;
+    for (int pass = 0; pass < nbytes; ++pass) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_sort_hist, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur], shift,
+                           nblocks, hist);
+        SX_TRY(sx_scan_exclusive(ctx, hist, 256 * nblocks, offs));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur],
+                           idx[cur], shift, nblocks, offs, img[cur ^ 1], idx[cur ^ 1]);
+        cur ^= 1;
+    }
+    SX_HIP(hipGetLastError());
+    *cur_out = cur;
+    return SX_OK;
+}
+
 SX_API int sx_argsort_desc_dev(sx_ctx *ctx, int64_t n, const double *key, int64_t *idx_out) {
     SX_ENTER(ctx);
     SX_REQUIRE(n >= 0, "n < 0");
     SX_REQUIRE(n < INT32_MAX, "n exceeds the int32 payload range");
     if (n == 0) return SX_OK;
     SX_REQUIRE(key && idx_out, "NULL argument");
-    const int64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+    const int64_t nblocks = sx_sort_blocks(n);
     hipStream_t s = ctx->stream;
     // double buffers and histograms live in the context's second grow-only block (the scan helper works
     // in the first one): no allocation and no host synchronisation per call once the block is large enough
@@ -143,15 +168,7 @@ SX_API int sx_argsort_desc_dev(sx_ctx *ctx, int64_t n, const double *key, int64_
 
     hipLaunchKernelGGL(k_sort_init, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, key, img[0], idx[0]);
     int cur = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_sort_hist, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur], shift,
-                           nblocks, hist);
-        SX_TRY(sx_scan_exclusive(ctx, hist, 256 * nblocks, offs));
-        hipLaunchKernelGGL(k_sort_scatter, dim3(static_cast<unsigned>(nblocks)), dim3(SX_WG), 0, s, n, img[cur],
-                           idx[cur], shift, nblocks, offs, img[cur ^ 1], idx[cur ^ 1]);
-        cur ^= 1;
-    }
+    SX_TRY(sx_sort_pairs(ctx, n, img, idx, hist, offs, 8, &cur));
     hipLaunchKernelGGL(k_sort_reverse, dim3(grid1d(n)), dim3(SX_WG), 0, s, n, idx[cur], idx_out);
     SX_HIP(hipGetLastError());
     return SX_OK;

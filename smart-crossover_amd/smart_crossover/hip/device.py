@@ -369,6 +369,28 @@ class DeviceMatrix:
         _l.check(self.ctx._lib.sx_matrix_download_csr(self.handle, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
         return sp.csr_matrix((val, col, rowptr), shape=(m, n))
 
+    def rowblock(self, download: bool = False):
+        """Column-blocked row layout of the matrix (csrc/sx_rowblock.h) under the context's "rowblock"
+        option, built now if due: a dict with the counts and, with ``download``, the arrays; None when the
+        matrix uses the plain row walk."""
+        info = (C.c_int64 * 6)()
+        _l.check(self.ctx._lib.sx_matrix_rowblock_info(self.ctx.handle, self.handle, info))
+        nst, ncells, nchunks, nent, windowed, stride = (int(v) for v in info)
+        if nst == 0:
+            return None
+        out = dict(nst=nst, ncells=ncells, nchunks=nchunks, nent=nent, windowed=windowed, rs_stride=stride)
+        if download:
+            st = np.zeros(nst, dtype=[("row0", "<i8"), ("chunk0", "<i8"), ("nrows", "<i4"), ("nchunks", "<i4")])
+            ch = np.zeros(nchunks, dtype=[("e0", "<i8"), ("ne", "<i4"), ("col0", "<i4"), ("cell", "<i4"), ("base", "<i4"),
+                                          ("fresh", "<i4"), ("pad", "<i4")])
+            rs = np.zeros(ncells * stride, dtype=np.uint16)
+            idx = np.zeros(nent + 8, dtype=np.int32)
+            val = np.zeros(nent + 8, dtype=np.float64)
+            _l.check(self.ctx._lib.sx_matrix_rowblock_download(self.ctx.handle, self.handle, st.ctypes.data, ch.ctypes.data,
+                                                               rs.ctypes.data, idx.ctypes.data, val.ctypes.data))
+            out.update(st=st, chunks=ch, rowstart=rs.reshape(ncells, stride), idx=idx, val=val)
+        return out
+
     def free(self) -> None:
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.sx_matrix_destroy(self.handle)

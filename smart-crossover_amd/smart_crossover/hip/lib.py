@@ -82,6 +82,8 @@ PROTOTYPES = {
     "sx_matrix_dims": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sx_matrix_arrays": (_int, [_vp] + [C.POINTER(_vp)] * 6),
     "sx_matrix_download_csr": (_int, [_vp, _vp, _vp, _vp]),
+    "sx_matrix_rowblock_info": (_int, [_vp, _vp, _vp]),
+    "sx_matrix_rowblock_download": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_score_columns_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "sx_score_columns": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "sx_score_rows_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),

@@ -63,6 +63,10 @@ def _ctx():
 
 
 def _canonical(A) -> sp.csr_matrix:
+    """A as canonical CSR; the *same object* when it already is one (the device copy is cached per object:
+    a fresh wrapper on every call would re-upload the matrix each time)."""
+    if sp.isspmatrix_csr(A) and A.has_canonical_format:
+        return A
     A = sp.csr_matrix(A)
     if not A.has_canonical_format:
         A = A.copy()
@@ -79,7 +83,8 @@ class _ResidentMatrix:
         self.dev = None
 
     def get(self, A: sp.csr_matrix):
-        key = (id(A), A.shape, A.nnz)
+        from smart_crossover.hip.resident import matrix_fingerprint
+        key = matrix_fingerprint(A)      # addresses and sizes of the three arrays, not the wrapper's id
         if self.key != key or self.dev is None or self.dev.handle is None:
             if self.dev is not None:
                 self.dev.free()

@@ -46,7 +46,10 @@ class HipCaller(SolverCaller):
 
     def read_genlp(self, genlp: GeneralLP) -> None:
         self._load(genlp.A, genlp.b, genlp.c, genlp.l, genlp.u, np.asarray(genlp.sense) == "<")
-        self._resident = getattr(genlp, "_sx_resident", None)
+        # the LP's device residency, validated against the matrix it holds NOW: resident_for() rebuilds it
+        # when lp.A was rebound since the last device call (a stale copy would silently solve the old matrix)
+        from smart_crossover.hip.resident import resident_for
+        self._resident = resident_for(genlp) if getattr(genlp, "_sx_resident", None) is not None else None
         self._col_ids = self._session_holder = self._dev_matrix = None
 
     def read_stdlp(self, stdlp: StandardLP) -> None:
@@ -86,13 +89,15 @@ class HipCaller(SolverCaller):
     # -- runs ----------------------------------------------------------------------------------
     def _solve(self) -> None:
         from smart_crossover.hip.device import default_context
+        from smart_crossover.hip.resident import matrix_fingerprint
         ctx = default_context()
         m, n = self._A.shape
         res = getattr(self, "_resident", None)
         given = getattr(self, "_dev_matrix", None)
         if given is not None and given.shape == (m, n) and given.handle is not None and given.ctx is ctx:
             dA, own = given, False                      # built on the device by the manager's gather
-        elif res is not None and res.A.shape == (m, n) and res.A.handle is not None:
+        elif (res is not None and res.A.shape == (m, n) and res.A.handle is not None
+              and res.fingerprint == matrix_fingerprint(self._A)):
             dA, own = res.A, False
         else:
             dA, own = ctx.matrix(self._A), True
