@@ -277,7 +277,8 @@ def main():
     k2_ms = float(np.mean([ctx.marker_elapsed(5 * i + 1, 5 * i + 2) for i in range(n_marked)]))
     k10_ms = float(np.mean([ctx.marker_elapsed(5 * i + 3, 5 * i + 4) for i in range(n_marked)]))
     k2_bytes = 12 * sh.row_block.nnz + 8 * n_tot + 33 * m_loc
-    k10_bytes = 12 * sh.col_block.nnz + 25 * n_loc + 8 * m           # K1 bytes - 24 n (no x,l,u,s_d,code; vbasis in)
+    # K10 as the step calls it (rc_out = None): entries 12 nnz, colptr 8 n, c 8 n, vbasis n, y 8 m -- no 8-byte store
+    k10_bytes = 12 * sh.col_block.nnz + 17 * n_loc + 8 * m
     k1_avg_s = float(np.mean(k1_ms)) / 1e3
     nnz_loc = sh.col_block.nnz
     k1_bytes = 12 * nnz_loc + 49 * n_loc + 8 * m        # K1 algorithmic bytes

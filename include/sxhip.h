@@ -71,6 +71,9 @@ int sx_ctx_sync(sx_ctx *ctx);
  * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]),
  * "spx_pricing" (entering variable of sx_simplex_solve*: 0 = Dantzig, largest reduced cost; 1 = Devex
  * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices),
+ * "spx_check" (pivots between two checks of A x + s = b against the explicit inverse's drift, a multiple of 64,
+ * default 2048; a failed check rebuilds the inverse from the basis columns) and "spx_force_reinvert" (0/1,
+ * tests: rebuild at every check),
  * "rowblock" (column-blocked copy of the rows for the row walk of sx_score_rows and the projector CG:
  * -1 auto [default: built on first use for matrices of >= 4M entries when at least half of them fall into
  * column blocks dense enough for an LDS window], 0 off, 1 whenever the matrix admits it; results are
@@ -309,17 +312,21 @@ int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const d
  * (solver_caller/solving.py:32-68; call sites lp_methods/algorithms.py:69-74 and
  * network_methods/net_manager.py:222,468):
  *     min c^T x   s.t.  (A x)_i = b_i  (row_is_lt[i] == 0)  or  <= b_i  (== 1),   l <= x <= u
- * Bounded revised primal simplex, two phases, explicit dense basis inverse in HBM (m <= 16384, else
- * SX_ERR_UNSUPPORTED) updated once per batch of 32 pivots, Devex pricing with Bland fallback (options
- * "spx_defer", "spx_pricing" above).  vbasis_in[n] / cbasis_in[m] (both or
- * neither; Gurobi codes 0 basic, -1 lower, -2 upper, -3 free / 0 basic, -1 non-basic) give a warm
- * start; a singular or primal-infeasible warm basis is dropped.  Outputs (device, any may be NULL):
- * x[n], y[m] with reduced cost = c - A^T y, vbasis[n], cbasis[m].  Blocking.  All arrays device. */
+ * Bounded revised primal simplex, two phases, explicit dense basis inverse in HBM (8 m^2 bytes must fit the
+ * free HBM, else SX_ERR_UNSUPPORTED) updated once per batch of 32 pivots and rebuilt from the basis columns
+ * whenever A x + s = b fails its periodic check, Devex pricing with Bland fallback (options "spx_defer",
+ * "spx_pricing", "spx_check" above).  vbasis_in[n] / cbasis_in[m] (both or neither; Gurobi codes 0 basic,
+ * -1 lower, -2 upper, -3 free or superbasic / 0 basic, -1 non-basic) give a warm start: its columns are
+ * pivoted in where they find a row, and a basis that is not primal feasible goes through phase 1 (bound
+ * violations of basic structurals and logicals alike are driven out) instead of being dropped.  status 0 is
+ * only reported for a point that satisfies A x + s = b to feas_tol (relative to 1 + max|b|).  Outputs
+ * (device, any may be NULL): x[n], y[m] with reduced cost = c - A^T y, vbasis[n], cbasis[m].  Blocking.  All
+ * arrays device. */
 typedef struct sx_simplex_result {
     int64_t status;          /* 0 optimal, 1 infeasible, 2 unbounded, 3 iteration limit, 4 numerical trouble */
     int64_t iters;           /* pivots and bound flips, both phases */
     int64_t phase1_iters;
-    int64_t warm_start_used; /* 1 when the given basis was installed and primal feasible */
+    int64_t warm_start_used; /* 1 when the given basis was installed, 2 when a session's inverse was reused */
     double obj;              /* c^T x */
     double max_violation;    /* largest bound violation of a basic variable at exit */
 } sx_simplex_result;
@@ -327,6 +334,19 @@ int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const
                          const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
                          const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
                          double *x, double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
+
+/* Crossover proper (what Gurobi's barrier + crossover does for the re-solve of lp_methods/algorithms.py:50-54):
+ * start from the interior point x_start[n] -- every column coded 0 or -3 in vbasis_in sits at its x_start
+ * value, clipped to its bounds, as a superbasic variable; the slack of a '<' row is b - A x_start; logicals
+ * coded 0 in cbasis_in keep their rows, the other rows go to the columns coded 0 that can take them -- so the
+ * first basic solution is the point itself, and the primal simplex then pushes the superbasic variables to a
+ * bound or into the basis one pivot at a time until it stands on an optimal vertex.  Same outputs as
+ * sx_simplex_solve_dev; a variable that is still superbasic at exit is reported as -3. */
+int sx_simplex_crossover_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                             const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
+                             const int8_t *cbasis_in, const double *x_start, int64_t max_iter, double feas_tol,
+                             double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
+                             sx_simplex_result *result);
 
 /* ------------------------------------------------------------------ entropic OT warm start
  * The step before the OT crossover in the reference's driver (scripts/run_network_crossover.py:95-97:

@@ -101,6 +101,11 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "rowblock")) {
         SX_REQUIRE(value >= -1 && value <= 1, "rowblock must be -1 (auto), 0 (off) or 1 (whenever possible)");
         ctx->opt_rowblock = static_cast<int>(value);
+    } else if (!strcmp(key, "spx_check")) {
+        SX_REQUIRE(value >= 64 && value % 64 == 0, "spx_check must be a positive multiple of 64 pivots");
+        ctx->opt_spx_check = static_cast<int>(value);
+    } else if (!strcmp(key, "spx_force_reinvert")) {
+        ctx->opt_spx_force_reinvert = value ? 1 : 0;
     } else if (!strcmp(key, "spx_pricing")) {
         SX_REQUIRE(value == 0 || value == 1, "spx_pricing must be 0 (Dantzig) or 1 (Devex)");
         ctx->opt_spx_pricing = static_cast<int>(value);

@@ -64,6 +64,10 @@ constexpr double PIV_TOL = 1e-9; // smallest |pivot| accepted
 constexpr int BLAND_AFTER = 100;
 constexpr int SPX_DEFER = 32;    // pivots whose inverse updates are held back and folded in together
 
+// ST_FREE: non-basic and not at a bound -- a free variable at 0, or a *superbasic* one at the interior value
+// x[k] a starting point gave it (the reference's basis code -3).  Pricing lets it move either way; entering, it
+// can travel as far as its own bound in that direction.  A start in which every variable keeps the value of an
+// interior point and the simplex pushes the superbasic ones out one by one is the crossover proper.
 enum : int { ST_BASIC = 0, ST_LOWER = -1, ST_UPPER = -2, ST_FREE = -3 };
 
 struct SpxState {
@@ -86,9 +90,12 @@ struct Spx {
     uint8_t *relaxed; // logical with phase-1 bounds
     double *lo, *up, *cost, *x;
     double *w; // Devex reference weights (nullptr: Dantzig pricing)
-    // true data of the logicals / costs for the phase switch
+    // true data of the logicals / costs / structural bounds for the phase switch
     const uint8_t *row_lt;
     const double *c_true;
+    const double *l_true, *u_true;
+    // value a logical keeps when a structural takes its row while a basis is installed (nullptr: it goes to 0)
+    double *s_keep;
     // per row
     int32_t *head;
     double *y, *d, *rho, *rhs, *b;
@@ -399,8 +406,9 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
         const bool none = j < 0 || s <= 0.0;
         if (!none) {
             const int stq = P.status[j];
-            range = P.up[j] - P.lo[j];
             dirq = (stq == ST_LOWER) ? 1 : (stq == ST_UPPER) ? -1 : (rc < 0 ? 1 : -1);
+            // from a bound: the width of the box; from an interior value (superbasic): what is left of it
+            range = (stq == ST_FREE) ? ((dirq > 0) ? P.up[j] - P.x[j] : P.x[j] - P.lo[j]) : P.up[j] - P.lo[j];
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (none) {
@@ -455,8 +463,12 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
             if (ratio < 0.0) ratio = 0.0; // slightly infeasible basic: degenerate step
             if (ratio < INFINITY) best = RatioCand{ratio, fabs(delta), acc, static_cast<int>(i), hk};
         } else if (hk >= P.n && fabs(acc) > PIV_TOL) { // crash: row still held by a logical, usable pivot
-            const double pref = (crash_cb && crash_cb[hk - P.n] == 0) ? 1e-6 : 1.0;
-            best = RatioCand{-fabs(acc) * pref, 0.0, acc, static_cast<int>(i), hk}; // smallest t = largest weight
+            const bool kept = crash_cb && crash_cb[hk - P.n] == 0; // the target basis keeps this logical
+            const double pref = kept ? 1e-6 : 1.0;
+            // with a starting point the kept logicals are not displaced at all: columns that find no other row
+            // stay superbasic at their value
+            if (!(kept && P.s_keep))
+                best = RatioCand{-fabs(acc) * pref, 0.0, acc, static_cast<int>(i), hk}; // smallest t = largest weight
         }
     }
     // One candidate per workgroup goes to memory; the launch that follows (k_spx_rho_update, k_spx_rho)
@@ -511,8 +523,10 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int q, int pending, in
         st->alpha = (br >= 0) ? pick.dval : 1.0;
         if (slot >= 0) P.er[slot] = br;
         if (br >= 0) { // nobody reads head / status in this launch
-            P.status[pick.hk] = ST_LOWER;
-            P.x[pick.hk] = 0.0;
+            const int i_log = pick.hk - static_cast<int>(P.n);
+            const double keep = (P.s_keep && P.row_lt[i_log]) ? P.s_keep[i_log] : 0.0;
+            P.status[pick.hk] = (keep > 0.0) ? ST_FREE : ST_LOWER; // superbasic slack at its value, or at 0
+            P.x[pick.hk] = (keep > 0.0) ? keep : 0.0;
             P.status[q] = ST_BASIC;
             P.head[br] = q;
         }
@@ -534,6 +548,7 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho(Spx P, int q, int pending, in
 struct CommitView {
     int q, dir, flip, r, k;    // entering variable, its direction, bound flip?, pivot row, leaving variable
     double t, alpha, xq, loq, upq, lok, upk, wq;
+    double lok_true, upk_true; // bounds the leaving variable gets back when it was relaxed for phase 1
     long long iters, n_relaxed;
     int relaxed_k, row_lt_k, degenerate_run;
 };
@@ -555,13 +570,19 @@ __device__ __forceinline__ CommitView commit_view(const Spx &P, int q, int dir, 
     v.upq = P.up[v.q];
     v.wq = P.w ? P.w[v.q] : 1.0;
     v.k = v.flip ? 0 : P.head[v.r];
-    v.lok = v.upk = 0.0;
+    v.lok = v.upk = v.lok_true = v.upk_true = 0.0;
     v.relaxed_k = v.row_lt_k = 0;
     if (!v.flip) {
         v.lok = P.lo[v.k];
         v.upk = P.up[v.k];
         v.relaxed_k = P.relaxed[v.k];
-        if (v.k >= P.n) v.row_lt_k = P.row_lt[v.k - P.n];
+        if (v.k >= P.n) {
+            v.row_lt_k = P.row_lt[v.k - P.n];
+            v.upk_true = v.row_lt_k ? INFINITY : 0.0;
+        } else if (v.relaxed_k) {
+            v.lok_true = P.l_true[v.k];
+            v.upk_true = P.u_true[v.k];
+        }
     }
     return v;
 }
@@ -590,13 +611,16 @@ __device__ __forceinline__ void spx_commit(const Spx &P, const CommitView &v, in
         P.x[q] = v.xq + v.dir * v.t;
         const int k = v.k;
         const bool to_lower = v.dir * v.alpha > 0; // x_k was decreasing
-        if (v.relaxed_k) { // a phase-1 logical that reached feasibility gets its true bounds back
+        if (v.relaxed_k) {
+            // a variable relaxed for phase 1 has reached the bound it violated: it gets its true bounds back
+            // and stays there.  Relaxed above its upper bound U it lived in [U, inf) and leaves decreasing,
+            // at U; relaxed below its lower bound L it lived in (-inf, L] and leaves increasing, at L.
             P.relaxed[k] = 0;
-            P.lo[k] = 0.0;
-            P.up[k] = v.row_lt_k ? INFINITY : 0.0;
-            P.cost[k] = 0.0;
-            P.x[k] = 0.0;
-            P.status[k] = ST_LOWER;
+            P.lo[k] = v.lok_true;
+            P.up[k] = v.upk_true;
+            P.cost[k] = 0.0; // phase 1: only relaxed variables carry a cost
+            P.x[k] = to_lower ? v.upk_true : v.lok_true;
+            P.status[k] = to_lower ? ST_UPPER : ST_LOWER;
             st->n_relaxed = v.n_relaxed - 1;
         } else {
             P.status[k] = to_lower ? ST_LOWER : ST_UPPER;
@@ -868,28 +892,33 @@ __global__ __launch_bounds__(SX_WG) void k_spx_btran(Spx P) {
     }
 }
 
-// phase 1: relax basic logicals that violate their true bounds; phase-1 cost = distance to feasibility
-__global__ void k_spx_phase1_setup(Spx P, double ftol) {
+// phase 1: relax every basic variable that violates a bound -- above its upper bound U it gets [U, inf) and
+// cost +1, below its lower bound L it gets (-inf, L] and cost -1 -- so that the phase-1 objective is the sum
+// of the bound violations; a relaxed variable that reaches the violated bound leaves the basis there and
+// gets its true bounds back (spx_commit).  Works from any basis, not only the all-logical one.
+__global__ __launch_bounds__(SX_WG) void k_spx_phase1_setup(Spx P, double ftol) {
     long long cnt = 0;
-    for (int64_t i = 0; i < P.m; ++i) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < P.m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
         const int k = P.head[i];
-        if (k < P.n) continue;
-        const double v = P.x[k];
-        if (v > P.up[k] + ftol) { // '=' row with positive residual
-            P.lo[k] = 0.0;
+        const double v = P.x[k], lo = P.lo[k], up = P.up[k];
+        if (v > up + ftol) {
+            P.lo[k] = up;
             P.up[k] = INFINITY;
             P.cost[k] = 1.0;
             P.relaxed[k] = 1;
             ++cnt;
-        } else if (v < P.lo[k] - ftol) {
+        } else if (v < lo - ftol) {
+            P.up[k] = lo;
             P.lo[k] = -INFINITY;
-            P.up[k] = 0.0;
             P.cost[k] = -1.0;
             P.relaxed[k] = 1;
             ++cnt;
         }
     }
-    P.st->n_relaxed = cnt;
+    cnt = sx_wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long *>(&P.st->n_relaxed),
+                                                  static_cast<unsigned long long>(cnt));
 }
 
 // infeasibility of the current basic solution: max bound violation over basic variables, and the
@@ -899,8 +928,8 @@ __global__ __launch_bounds__(1024) void k_spx_measure(Spx P, double *out /* [0]=
     for (int i = threadIdx.x; i < P.m; i += 1024) {
         const int k = P.head[i];
         const double v = P.x[k];
-        if (P.relaxed[k]) {
-            p1 += fabs(v);
+        if (P.relaxed[k]) { // distance to the bound it violates (the finite end of its relaxed range)
+            p1 += (P.lo[k] > -INFINITY) ? fmax(v - P.lo[k], 0.0) : fmax(P.up[k] - v, 0.0);
         } else {
             if (v < P.lo[k]) viol = fmax(viol, P.lo[k] - v);
             if (v > P.up[k]) viol = fmax(viol, v - P.up[k]);
@@ -940,6 +969,11 @@ __global__ __launch_bounds__(SX_WG) void k_spx_phase2_setup(Spx P) {
         if (P.w) P.w[k] = 1.0; // new objective: new reference framework
         if (k < P.n) {
             P.cost[k] = P.c_true[k];
+            if (P.relaxed[k]) {
+                P.relaxed[k] = 0;
+                P.lo[k] = P.l_true[k];
+                P.up[k] = P.u_true[k];
+            }
         } else {
             P.cost[k] = 0.0;
             if (P.relaxed[k]) {
@@ -967,6 +1001,7 @@ __global__ void k_spx_reset_state(Spx P) {
     st->q = -1;
     st->r = -1;
     st->dvx_on = 0;
+    st->n_relaxed = 0;
 }
 
 // outputs in the reference's conventions
@@ -983,6 +1018,83 @@ __global__ __launch_bounds__(SX_WG) void k_spx_export(Spx P, double *__restrict_
             if (y_out) y_out[i] = P.y[i];
             if (cb) cb[i] = (P.status[k] == ST_BASIC) ? 0 : -1;
         }
+    }
+}
+
+// true residual of the current point, all variables: r_i = b_i - sum_j a_ij x_j - s_i; out[0] = max |r_i|,
+// out[1] = max |b_i| (both as the bit pattern of a non-negative double, which orders like an integer)
+__global__ __launch_bounds__(SX_WG) void k_spx_residual(Spx P, const int64_t *__restrict__ tiles, int64_t ntiles,
+                                                        const int64_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ colidx,
+                                                        const double *__restrict__ val,
+                                                        unsigned long long *__restrict__ out) {
+    __shared__ sx_walk_lds<1, SPX_CHUNK> lds;
+    double worst = 0.0, bmax = 0.0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        double acc[1];
+        int64_t i;
+        bool valid;
+        sx_segwalk<1, SPX_CHUNK>(tiles, t, rowptr, colidx, val, StageDot{P.x}, lds, i, valid, acc);
+        if (valid) {
+            const double r = fabs(P.b[i] - acc[0] - P.x[P.n + i]);
+            worst = (r > worst || r != r) ? (r != r ? INFINITY : r) : worst; // NaN counts as the worst residual
+            bmax = fmax(bmax, fabs(P.b[i]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        worst = fmax(worst, __shfl_down(worst, o, 64));
+        bmax = fmax(bmax, __shfl_down(bmax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], static_cast<unsigned long long>(__double_as_longlong(worst)));
+        atomicMax(&out[1], static_cast<unsigned long long>(__double_as_longlong(bmax)));
+    }
+}
+
+// back to the all-logical basis without moving anything: every basic structural becomes superbasic at its
+// current value (it is about to be pivoted in again; if no row takes it, it stays where it is), every logical
+// basic, its current value remembered in s_keep for the moment a structural takes its row
+__global__ __launch_bounds__(SX_WG) void k_spx_logical_basis(Spx P) {
+    const int64_t N = P.n + P.m;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < N;
+         k += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        if (k < P.n) {
+            if (P.status[k] == ST_BASIC) P.status[k] = ST_FREE;
+        } else {
+            P.s_keep[k - P.n] = P.x[k];
+            P.status[k] = ST_BASIC;
+            P.head[k - P.n] = static_cast<int32_t>(k);
+        }
+    }
+}
+
+// starting point: structurals the warm basis wants basic (code 0) or superbasic (-3) take the point's value,
+// clipped to their bounds, as superbasic variables -- pivoting them in will not move them -- and the slack
+// b - A x of every row is remembered for the logical that loses its row
+__global__ __launch_bounds__(SX_WG) void k_spx_apply_start(Spx P, const int8_t *__restrict__ vb,
+                                                           const double *__restrict__ x_start) {
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < P.n;
+         k += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const int code = vb[k];
+        if (code == ST_BASIC || code == ST_FREE) {
+            const double v = x_start[k];
+            P.status[k] = ST_FREE;
+            P.x[k] = (v == v) ? fmin(fmax(v, P.lo[k]), P.up[k]) : ((P.lo[k] > -INFINITY) ? P.lo[k] : 0.0);
+        }
+    }
+}
+__global__ __launch_bounds__(SX_WG) void k_spx_start_slacks(Spx P, const int64_t *__restrict__ tiles, int64_t ntiles,
+                                                            const int64_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ colidx,
+                                                            const double *__restrict__ val) {
+    __shared__ sx_walk_lds<1, SPX_CHUNK> lds;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        double acc[1];
+        int64_t i;
+        bool valid;
+        sx_segwalk<1, SPX_CHUNK>(tiles, t, rowptr, colidx, val, StageDot{P.x}, lds, i, valid, acc);
+        if (valid) P.s_keep[i] = P.b[i] - acc[0];
     }
 }
 
@@ -1083,13 +1195,19 @@ SX_API int sx_simplex_session_destroy(sx_simplex_session *session) {
     return SX_OK;
 }
 
+static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *A, const double *b, const double *c,
+                     const double *l, const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
+                     const int8_t *cbasis_in, const int64_t *col_ids, const double *x_start, int64_t max_iter,
+                     double feas_tol, double opt_tol, double *x_out, double *y_out, int8_t *vbasis_out,
+                     int8_t *cbasis_out, sx_simplex_result *result);
+
 SX_API int sx_simplex_solve_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
                                 const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
                                 const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol,
                                 double *x_out, double *y_out, int8_t *vbasis_out, int8_t *cbasis_out,
                                 sx_simplex_result *result) {
-    return sx_simplex_solve_session_dev(ctx, nullptr, A, b, c, l, u, row_is_lt, vbasis_in, cbasis_in, nullptr, max_iter,
-                                        feas_tol, opt_tol, x_out, y_out, vbasis_out, cbasis_out, result);
+    return spx_solve(ctx, nullptr, A, b, c, l, u, row_is_lt, vbasis_in, cbasis_in, nullptr, nullptr, max_iter, feas_tol,
+                     opt_tol, x_out, y_out, vbasis_out, cbasis_out, result);
 }
 
 SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *A, const double *b,
@@ -1098,6 +1216,26 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
                                         int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
                                         double *y_out, int8_t *vbasis_out, int8_t *cbasis_out,
                                         sx_simplex_result *result) {
+    return spx_solve(ctx, session, A, b, c, l, u, row_is_lt, vbasis_in, cbasis_in, col_ids, nullptr, max_iter, feas_tol,
+                     opt_tol, x_out, y_out, vbasis_out, cbasis_out, result);
+}
+
+SX_API int sx_simplex_crossover_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                    const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
+                                    const int8_t *cbasis_in, const double *x_start, int64_t max_iter, double feas_tol,
+                                    double opt_tol, double *x_out, double *y_out, int8_t *vbasis_out,
+                                    int8_t *cbasis_out, sx_simplex_result *result) {
+    SX_REQUIRE(x_start != nullptr && vbasis_in != nullptr && cbasis_in != nullptr,
+               "sx_simplex_crossover_dev needs a starting point and a basis guess");
+    return spx_solve(ctx, nullptr, A, b, c, l, u, row_is_lt, vbasis_in, cbasis_in, nullptr, x_start, max_iter, feas_tol,
+                     opt_tol, x_out, y_out, vbasis_out, cbasis_out, result);
+}
+
+static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *A, const double *b, const double *c,
+                     const double *l, const double *u, const uint8_t *row_is_lt, const int8_t *vbasis_in,
+                     const int8_t *cbasis_in, const int64_t *col_ids, const double *x_start, int64_t max_iter,
+                     double feas_tol, double opt_tol, double *x_out, double *y_out, int8_t *vbasis_out,
+                     int8_t *cbasis_out, sx_simplex_result *result) {
     SX_ENTER(ctx);
     SX_REQUIRE(session == nullptr || session->ctx == ctx, "the session belongs to another context");
     SX_REQUIRE(A && b && c && l && u && row_is_lt && result, "NULL argument");
@@ -1105,9 +1243,17 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     SX_REQUIRE((vbasis_in == nullptr) == (cbasis_in == nullptr), "vbasis_in and cbasis_in go together");
     memset(result, 0, sizeof(*result));
     const int64_t m = A->m, n = A->n, N = n + m;
-    if (m > 16384) {
-        sx_set_error("sx_simplex_solve: m = %lld exceeds the dense-inverse limit of 16384 rows", (long long)m);
-        return SX_ERR_UNSUPPORTED;
+    {   // the basis inverse is an explicit dense m x m matrix: it has to fit the HBM that is free now
+        size_t free_b = 0, total_b = 0;
+        SX_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double need = 8.0 * static_cast<double>(m) * static_cast<double>(m) + 600.0 * static_cast<double>(m) +
+                            40.0 * static_cast<double>(N);
+        const bool have_inverse = session && session->m == m && session->Binv != nullptr;
+        if (!have_inverse && need > 0.9 * static_cast<double>(free_b)) {
+            sx_set_error("sx_simplex_solve: the dense basis inverse of %lld rows needs %.1f GB, %.1f GB of HBM are free",
+                         (long long)m, need / 1e9, static_cast<double>(free_b) / 1e9);
+            return SX_ERR_UNSUPPORTED;
+        }
     }
     if (max_iter <= 0) max_iter = 50 * (m + n) + 1000;
     hipStream_t s = ctx->stream;
@@ -1121,7 +1267,7 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     {
         // everything below except a session-less inverse: 34 B per variable, 44 B per row, pricing partials
         const size_t um = static_cast<size_t>(m), uN = static_cast<size_t>(N);
-        size_t bytes = 34 * uN + 48 * um + 24 * (static_cast<size_t>(SPX_GRID) + um / 64 + 64) + 32 * 256 + 4096;
+        size_t bytes = 34 * uN + 56 * um + 24 * (static_cast<size_t>(SPX_GRID) + um / 64 + 64) + 32 * 256 + 4096;
         if (!session) bytes += sizeof(double) * um * um + 256;
         if (defer) bytes += 2 * sizeof(double) * um * SPX_DEFER + 1024;
         bytes += 32 * (um / SX_WG + 2) + 1024; // ratio candidates, tickets
@@ -1133,6 +1279,8 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     P.n = n;
     P.row_lt = row_is_lt;
     P.c_true = c;
+    P.l_true = l;
+    P.u_true = u;
     SX_TRY(mem.get(static_cast<size_t>(N), &P.status));
     SX_TRY(mem.get(static_cast<size_t>(N), &P.relaxed));
     SX_TRY(mem.get(static_cast<size_t>(N), &P.lo));
@@ -1146,6 +1294,9 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     SX_TRY(mem.get(static_cast<size_t>(m), &P.d));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.rho));
     SX_TRY(mem.get(static_cast<size_t>(m), &P.rhs));
+    double *s_keep_buf = nullptr;
+    SX_TRY(mem.get(static_cast<size_t>(m), &s_keep_buf));
+    P.s_keep = nullptr;
     if (session) { // the inverse outlives the call
         if (session->m != m || session->Binv == nullptr) {
             if (session->Binv) SX_HIP(hipFree(session->Binv));
@@ -1220,6 +1371,70 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         hipLaunchKernelGGL(k_spx_identity, dim3(gMM), dim3(SX_WG), 0, s, P);
     };
 
+    // ---- helpers of the starting basis and of numerical hygiene
+    unsigned long long *resid_dev = nullptr;
+    SX_TRY(mem.get(2, &resid_dev));
+    int8_t *vb_now = nullptr, *cb_now = nullptr; // the current basis in the reference's codes (re-inversion)
+    SX_TRY(mem.get(static_cast<size_t>(n), &vb_now));
+    SX_TRY(mem.get(static_cast<size_t>(m), &cb_now));
+    // max_i |b_i - (A x)_i - s_i| / (1 + max |b|): what the explicit inverse has drifted by
+    auto residual = [&](double *rel) -> int {
+        SX_HIP(hipMemsetAsync(resid_dev, 0, 2 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_spx_residual, dim3(gR), dim3(SX_WG), 0, s, P, A->csr_tiles, A->n_csr_tiles, A->csr_ptr,
+                           A->csr_idx, A->csr_val, resid_dev);
+        unsigned long long h[2] = {0, 0};
+        SX_HIP(hipMemcpyAsync(h, resid_dev, sizeof(h), hipMemcpyDeviceToHost, s));
+        SX_HIP(hipStreamSynchronize(s));
+        double worst, bmax;
+        memcpy(&worst, &h[0], sizeof(double));
+        memcpy(&bmax, &h[1], sizeof(double));
+        *rel = worst / (1.0 + bmax);
+        return SX_OK;
+    };
+    const double resid_tol = feas_tol;
+    // pivot the structural columns flagged basic in vb_host (n codes) into the all-logical basis (identity
+    // inverse): for each column the largest available pivot among the rows still held by a logical, rows whose
+    // logical the target basis keeps (cb_dev code 0) only as a last resort; a column without a usable row stays
+    // non-basic
+    auto install = [&](const std::vector<int8_t> &vb_host, const int8_t *cb_dev) {
+        int slot = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            if (vb_host[static_cast<size_t>(j)] != ST_BASIC) continue;
+            hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val,
+                               static_cast<int>(j), 0, defer ? slot : 0, cb_dev);
+            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P, static_cast<int>(j), defer ? slot : 0,
+                               defer ? slot : -1);
+            if (!defer) {
+                hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
+            } else if (++slot == SPX_DEFER) {
+                fold(slot);
+                slot = 0;
+            }
+        }
+        if (defer && slot > 0) fold(slot);
+        hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
+    };
+    // rebuild the inverse of the CURRENT basis from its columns (the running inverse has only ever seen
+    // rank-one updates and drifts): all logicals back in, identity, the basic structurals pivoted in again
+    int64_t n_reinvert = 0;
+    std::vector<int8_t> vb_host;
+    auto reinvert = [&]() -> int {
+        hipLaunchKernelGGL(k_spx_export, dim3(gN), dim3(SX_WG), 0, s, P, static_cast<double *>(nullptr),
+                           static_cast<double *>(nullptr), vb_now, cb_now);
+        vb_host.resize(static_cast<size_t>(n));
+        SX_HIP(hipMemcpyAsync(vb_host.data(), vb_now, static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
+        SX_HIP(hipStreamSynchronize(s));
+        P.s_keep = s_keep_buf; // nothing moves: displaced logicals keep the value they have now
+        hipLaunchKernelGGL(k_spx_logical_basis, dim3(gN), dim3(SX_WG), 0, s, P);
+        hipLaunchKernelGGL(k_spx_identity, dim3(gMM), dim3(SX_WG), 0, s, P);
+        if (defer) SX_HIP(hipMemsetAsync(P.er, 0xff, sizeof(int32_t) * SPX_DEFER, s));
+        install(vb_host, cb_now);
+        P.s_keep = nullptr;
+        ++n_reinvert;
+        SX_HIP(hipGetLastError());
+        return SX_OK;
+    };
+
     // ---- starting basis
     bool warm = false, reused = false;
     std::vector<int8_t> vb;
@@ -1269,8 +1484,11 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             hipLaunchKernelGGL(k_spx_install_head, dim3(gM), dim3(SX_WG), 0, s, P, head_dev);
             hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
             refresh(true);
-            SX_TRY(measure()); // synchronises: head_new may go out of scope afterwards
-            reused = warm = host_meas[0] <= feas_tol * 10;
+            // the kept inverse is accepted when it still reproduces the constraints: x_B = Binv (b - N x_N) must
+            // satisfy A x + s = b (a basis that is merely infeasible for the new bounds goes through phase 1)
+            double rel = 0.0;
+            SX_TRY(residual(&rel)); // synchronises: head_new may go out of scope afterwards
+            reused = warm = rel <= resid_tol;
         }
     }
     if (session) session->valid = false; // until this solve has left a basis behind
@@ -1284,31 +1502,23 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     double t_crash_ms = 0.0;
     if (vbasis_in && !reused) {
         hipLaunchKernelGGL(k_spx_apply_vbasis, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in);
-        int slot = 0;
-        for (int64_t j = 0; j < n; ++j) {
-            if (vb[static_cast<size_t>(j)] != ST_BASIC) continue;
-            hipLaunchKernelGGL(k_spx_ftran, dim3(gM), dim3(SX_WG), 0, s, P, A->csc_ptr, A->csc_idx, A->csc_val,
-                               static_cast<int>(j), 0, defer ? slot : 0, cbasis_in);
-            hipLaunchKernelGGL(k_spx_rho, dim3(gM), dim3(SX_WG), 0, s, P, static_cast<int>(j), defer ? slot : 0,
-                               defer ? slot : -1);
-            if (!defer) {
-                hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
-            } else if (++slot == SPX_DEFER) {
-                fold(slot);
-                slot = 0;
-            }
+        if (x_start) {
+            // crossover start: every variable keeps the value of the point -- columns the basis guess wants
+            // basic become superbasic at x_start and are then pivoted in where a row is free, the slack of a
+            // row a structural takes stays at b - A x_start -- so the first basic solution IS the point
+            P.s_keep = s_keep_buf;
+            hipLaunchKernelGGL(k_spx_apply_start, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, vbasis_in, x_start);
+            hipLaunchKernelGGL(k_spx_start_slacks, dim3(gR), dim3(SX_WG), 0, s, P, A->csr_tiles, A->n_csr_tiles,
+                               A->csr_ptr, A->csr_idx, A->csr_val);
         }
-        if (defer && slot > 0) fold(slot);
+        install(vb, cbasis_in);
+        P.s_keep = nullptr;
         if (trace) {
             const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
             fprintf(stderr, "[sx_simplex] warm basis: launches enqueued by %.2f ms\n", enq);
             t_crash_ms = since_enter();
         }
-        hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P);
-        refresh(true);
-        SX_TRY(measure());
-        warm = host_meas[0] <= feas_tol * 10;
-        if (!warm) cold_start(1); // singular or infeasible warm basis: start from the logicals
+        warm = true; // whatever could be pivoted in stays; infeasibilities go through phase 1
     }
     SX_HIP(hipGetLastError());
     const double t_start_ms = trace ? since_enter() : 0.0;
@@ -1366,6 +1576,16 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         }
     } graph_guard{graph, exec};
 
+    // x_B and y from scratch cost two passes over the m x m inverse, a pivot O(m): the interval grows with m
+    // so that the refresh stays a small share of the pivots between two of them (64 up to m = 2048, 2048 from
+    // m = 11.6k on); the residual check every "spx_check" pivots is the safety net either way
+    int64_t refresh_every = 64;
+    {
+        const double scale = static_cast<double>(m) / 2048.0;
+        int64_t want = static_cast<int64_t>(64.0 * scale * scale);
+        want = (want / 64) * 64;
+        refresh_every = want < 64 ? 64 : (want > 2048 ? 2048 : want);
+    }
     int64_t direct_pivots = 0; // over both phases
     auto run_phase = [&](int64_t budget) -> int {
         int64_t done_iters = 0;
@@ -1382,7 +1602,15 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
             SX_HIP(hipMemcpyAsync(&host, P.st, sizeof(host), hipMemcpyDeviceToHost, s));
             SX_HIP(hipStreamSynchronize(s));
             if (host.done || host.iters >= budget) return SX_OK;
-            if ((done_iters & 63) == 0) refresh(true); // numerical hygiene: x_B and y from scratch
+            if (done_iters % refresh_every == 0) refresh(true); // numerical hygiene: x_B and y from scratch
+            if (done_iters % ctx->opt_spx_check == 0) { // and the inverse itself, against the constraints
+                double rel = 0.0;
+                SX_TRY(residual(&rel));
+                if (!(rel <= resid_tol) || ctx->opt_spx_force_reinvert) {
+                    SX_TRY(reinvert());
+                    refresh(true);
+                }
+            }
         }
     };
 
@@ -1394,7 +1622,8 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
     if (host_meas[0] > feas_tol) {
         // ---- phase 1: minimise the infeasibility of the relaxed logicals
         hipLaunchKernelGGL(k_spx_struct_cost, dim3(grid1d(n)), dim3(SX_WG), 0, s, P, 0);
-        hipLaunchKernelGGL(k_spx_phase1_setup, dim3(1), dim3(1), 0, s, P, feas_tol);
+        hipLaunchKernelGGL(k_spx_reset_state, dim3(1), dim3(1), 0, s, P); // also zeroes the relaxed count
+        hipLaunchKernelGGL(k_spx_phase1_setup, dim3(gM), dim3(SX_WG), 0, s, P, feas_tol);
         hipLaunchKernelGGL(k_spx_btran, dim3(grid1d(m * 64)), dim3(SX_WG), 0, s, P);
         SX_TRY(run_phase(max_iter));
         phase1_iters = host.iters;
@@ -1413,11 +1642,26 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         }
     }
     if (status < 0) {
-        SX_TRY(run_phase(max_iter));
-        if (host.done == 1) status = 0;
-        else if (host.done == 2) status = 2;
-        else if (host.done == 3) status = 4;
-        else status = 3;
+        // phase 2, and the check the advisor asked for: "optimal" is only reported for a point that satisfies
+        // A x + s = b; if the running inverse has drifted, it is rebuilt from the basis columns and the phase
+        // resumed from the same basis (twice at most)
+        for (int attempt = 0; attempt < 3 && status < 0; ++attempt) {
+            SX_TRY(run_phase(max_iter));
+            if (host.done == 2) status = 2;
+            else if (host.done == 3) status = 4;
+            else if (host.done == 0) status = 3;
+            else {
+                refresh(true);
+                double rel = 0.0;
+                SX_TRY(residual(&rel));
+                if (rel <= resid_tol) status = 0;
+                else if (attempt == 2) status = 4;
+                else {
+                    SX_TRY(reinvert());
+                    refresh(true);
+                }
+            }
+        }
     }
     refresh(true);
     SX_TRY(measure());
@@ -1428,10 +1672,10 @@ SX_API int sx_simplex_solve_session_dev(sx_ctx *ctx, sx_simplex_session *session
         const double t_all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
         fprintf(stderr,
                 "[sx_simplex] m=%lld n=%lld start=%s: set-up %.2f ms, basis %.2f ms (columns installed by %.2f), "
-                "phases %.2f ms, %lld pivots (%lld in phase 1), status %d\n",
+                "phases %.2f ms, %lld pivots (%lld in phase 1), %lld re-inversions, status %d\n",
                 (long long)m, (long long)n, reused ? "kept inverse" : (vbasis_in ? (warm ? "crash" : "crash dropped") : "cold"),
                 t_setup_ms, t_start_ms - t_setup_ms, t_crash_ms > 0 ? t_crash_ms - t_setup_ms : 0.0, t_all - t_start_ms,
-                (long long)host.iters, (long long)phase1_iters, status);
+                (long long)host.iters, (long long)phase1_iters, (long long)n_reinvert, status);
     }
     result->status = status;
     result->iters = host.iters;

@@ -229,11 +229,18 @@ class Context:
 
     def simplex(self, A, b, c, l, u, row_is_lt, vbasis=None, cbasis=None, max_iter=0, feas_tol=1e-7, opt_tol=1e-7,
                 x=None, y=None, vbasis_out=None, cbasis_out=None, session: Optional["SimplexSession"] = None,
-                col_ids: Optional[np.ndarray] = None) -> "_l.SimplexResult":
+                col_ids: Optional[np.ndarray] = None, x_start=None) -> "_l.SimplexResult":
         """K16 (blocking): bounded primal simplex on the device; device pointers in and out.  With a
         ``session`` and stable column identifiers ``col_ids`` (host int64) the basis inverse of the
-        previous solve is reused when the warm basis is that solve's final basis."""
+        previous solve is reused when the warm basis is that solve's final basis.  With ``x_start`` (and a
+        basis guess) the solve is a crossover from that interior point (sx_simplex_crossover_dev)."""
         res = _l.SimplexResult()
+        if x_start is not None:
+            _l.check(self._lib.sx_simplex_crossover_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u),
+                                                        _ptr(row_is_lt), _ptr(vbasis), _ptr(cbasis), _ptr(x_start),
+                                                        int(max_iter), float(feas_tol), float(opt_tol), _ptr(x), _ptr(y),
+                                                        _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+            return res
         if session is None:
             _l.check(self._lib.sx_simplex_solve_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u),
                                                     _ptr(row_is_lt), _ptr(vbasis), _ptr(cbasis), int(max_iter),

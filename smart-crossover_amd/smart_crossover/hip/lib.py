@@ -110,6 +110,8 @@ PROTOTYPES = {
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
     "sx_simplex_solve_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                     C.POINTER(SimplexResult)]),
+    "sx_simplex_crossover_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                        C.POINTER(SimplexResult)]),
     "sx_sinkhorn_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,
                                C.POINTER(SinkhornResult)]),
     "sx_simplex_session_create": (_int, [_vp, C.POINTER(_vp)]),

@@ -4,10 +4,20 @@ seam -- ``solver="HIP"`` in ``solve_lp`` / ``solve_mcf`` / ``solve_ot`` / ``netw
 It serves the *simplex family* of methods ('default', 'simplex', 'primal_simplex', 'dual_simplex',
 'network_simplex' all run the bounded primal simplex) with Gurobi-style warm bases, i.e. the
 re-solves the crossover algorithms issue with a warm start (lp_methods/algorithms.py:69-74,
-network_methods/net_manager.py:222,468).  It has no interior-point method: 'barrier' raises
-NotImplementedError -- pair it with a barrier-capable backend through the composite name
-``"<barrier backend>+HIP"`` (e.g. ``"HGS+HIP"``): barrier runs go to the first backend, simplex runs
-to the device.  Size limit: 16384 rows (dense basis inverse in HBM).
+network_methods/net_manager.py:222,468).
+
+'barrier' with crossover -- the re-solve of the perturbed sub-problem, lp_methods/algorithms.py:50-54 --
+is served too, by a substitute: the reference's solvers run an interior-point method plus their own
+crossover there and ignore the warm start they are handed (quirk Q6); all the caller consumes is the optimal
+*vertex* and its basis, and the perturbed LP has a unique one.  The device has no interior-point method, so it
+takes the interior point it is handed (``crash_from_warm_start``: ``solve_problem`` passes the warm start
+on to backends that ask for it), turns it into a crash basis -- columns strictly between their bounds and
+slacks of inactive rows basic -- and starts the primal simplex AT that point (``sx_simplex_crossover_dev``:
+the columns that find no basis row stay superbasic at their interior value and are pushed out one pivot at a
+time, which is what a crossover does).  'barrier' *without* crossover (the initial solve, whose output is the interior point itself) is not
+available: pair the device with a barrier-capable backend through the composite name
+``"<barrier backend>+HIP"`` (e.g. ``"HGS+HIP"``).  Size limit: the dense basis inverse (8 m^2 bytes) must fit
+the free HBM, i.e. about 1.7e5 rows on an empty MI355X.
 """
 from __future__ import annotations
 
@@ -25,12 +35,17 @@ from smart_crossover.solver_caller.caller import SolverCaller, SolverSettings
 _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
 
+CRASH_MARGIN = 1e-6      # a column this far (relative) inside its bounds / a slack this large counts as basic
+
+
 class HipCaller(SolverCaller):
     solver_name = "HIP"
+    crash_from_warm_start = True     # solve_problem hands a 'barrier' run its warm start (see module docstring)
 
     def __init__(self, solver_settings: Optional[SolverSettings] = None) -> None:
         super().__init__(solver_settings)
         self._warm: Optional[Basis] = None
+        self._warm_point: Optional[Tuple[np.ndarray, np.ndarray]] = None
         self._res = None
         self._runtime = 0.0
         self._x = self._y = self._vb = self._cb = None
@@ -42,6 +57,7 @@ class HipCaller(SolverCaller):
         self._l, self._u = np.asarray(l, float), np.asarray(u, float)
         self._row_lt = np.asarray(row_lt, dtype=np.uint8)
         self._warm = None
+        self._warm_point = None
         self._res = None
 
     def read_genlp(self, genlp: GeneralLP) -> None:
@@ -84,7 +100,43 @@ class HipCaller(SolverCaller):
         self._warm = basis
 
     def add_warm_start_solution(self, start_solution: Tuple[np.ndarray, np.ndarray]) -> None:
-        pass                                    # a primal simplex starts from a basis, not from a point
+        # a primal simplex starts from a basis, not from a point: the point only serves the crash of run_barrier
+        self._warm_point = start_solution
+
+    def _crash_basis(self, ctx, dA) -> Optional[Basis]:
+        """Basis guess from the interior point handed over as warm start.  Candidates are the variables that
+        sit strictly inside their bounds: structural j with margin min(x_j - l_j, u_j - x_j), and the slack of a
+        '<' row with margin b_i - (A x)_i (row scoring kernel K2 on the device).  A vertex has room for m of
+        them; the perturbed objective of the crossover weighs a column by 1 / margin
+        (lp_methods/algorithms.py:148), so the ones it drives to a bound are, by and large, those with the
+        smallest margins: the m candidates with the largest margins are proposed as basic (codes 0), the other
+        interior ones stay superbasic at their value (-3 / a free row), everything else sits at its nearer bound."""
+        if self._warm_point is None:
+            return None
+        x = np.asarray(self._warm_point[0], dtype=np.float64)
+        m, n = self._A.shape
+        if x.size != n:
+            return None
+        with np.errstate(invalid="ignore"):
+            lo_gap, up_gap = x - self._l, self._u - x
+        margin = np.minimum(lo_gap, up_gap)
+        free = np.isinf(self._l) & np.isinf(self._u)
+        interior = (margin > CRASH_MARGIN * (1.0 + np.abs(x))) | free
+        s_p = ctx.empty(m, np.float64)
+        ctx.score_rows(dA, ctx.to_device(x), ctx.to_device(self._b), None, 0.0, s_p, None)
+        slack = s_p.download()
+        slack_in = self._row_lt.astype(bool) & (slack > CRASH_MARGIN * (1.0 + np.abs(self._b)))
+        score = np.concatenate([np.where(free, np.inf, np.where(interior, margin, -np.inf)),
+                                np.where(slack_in, slack, -np.inf)])
+        n_cand = int(np.count_nonzero(score > -np.inf))
+        thr = -np.inf
+        if n_cand > m:                     # more interior variables than a vertex can hold: keep the m largest
+            thr = np.partition(score, score.size - m)[score.size - m]
+        vb = np.where(lo_gap <= up_gap, -1, -2).astype(np.int64)
+        vb[interior] = -3
+        vb[interior & (score[:n] >= thr)] = 0
+        cb = np.where(slack_in & (score[n:] >= thr), 0, -1).astype(np.int64)
+        return Basis(vb, cb)
 
     # -- runs ----------------------------------------------------------------------------------
     def _solve(self) -> None:
@@ -104,7 +156,11 @@ class HipCaller(SolverCaller):
         put = lambda v: ctx.to_device(np.ascontiguousarray(v, dtype=np.float64))   # noqa: E731
         d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
         d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
-        vb_in = cb_in = None
+        vb_in = cb_in = x_start = None
+        if self._warm is None and getattr(self, "_want_crash", False):
+            self._warm = self._crash_basis(ctx, dA)
+            if self._warm is not None:          # crossover: start AT the interior point (superbasic columns)
+                x_start = ctx.to_device(np.ascontiguousarray(self._warm_point[0], dtype=np.float64))
         if self._warm is not None and self._warm.vbasis.size == n and self._warm.cbasis.size == m:
             vb_in = ctx.to_device(np.clip(self._warm.vbasis, -3, 0).astype(np.int8))
             cb_in = ctx.to_device(np.clip(self._warm.cbasis, -1, 0).astype(np.int8))
@@ -117,12 +173,19 @@ class HipCaller(SolverCaller):
         t0 = time.perf_counter()
         self._res = ctx.simplex(dA, put(self._b), put(self._c), put(self._l), put(self._u), ctx.to_device(self._row_lt),
                                 vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb,
-                                session=session, col_ids=col_ids)
+                                session=None if x_start is not None else session,
+                                col_ids=None if x_start is not None else col_ids, x_start=x_start)
         self._runtime = time.perf_counter() - t0
         self._x, self._y = d_x.download(), d_y.download()
         self._vb, self._cb = d_vb.download().astype(int), d_cb.download().astype(int)
         if own:
             dA.free()
+        if int(self._res.status) not in _STATUS:
+            # no usable vertex: say so here instead of letting the caller trip over a missing x / basis
+            why = {3: "hit the iteration limit", 4: "lost numerical accuracy (the basis inverse could not be repaired)"}
+            raise RuntimeError(f"HIP simplex {why.get(int(self._res.status), 'failed')} after {int(self._res.iters)} pivots "
+                               f"on a {m} x {n} problem (max bound violation {float(self._res.max_violation):.2e}); "
+                               "use solver='HGS' for this instance")
         self._log_summary(self._runtime, int(self._res.iters))
 
     def run_default(self) -> None:
@@ -131,9 +194,16 @@ class HipCaller(SolverCaller):
     run_simplex = run_primal_simplex = run_dual_simplex = run_network_simplex = run_default
 
     def run_barrier(self) -> None:
-        raise NotImplementedError("the HIP backend has no interior-point method; use e.g. solver='HGS+HIP'")
+        """'barrier' + crossover: vertex and basis by the primal simplex from a crash basis (module docstring)."""
+        self._want_crash = True
+        try:
+            self._solve()
+        finally:
+            self._want_crash = False
 
-    run_barrier_no_crossover = run_barrier
+    def run_barrier_no_crossover(self) -> None:
+        raise NotImplementedError("the HIP backend has no interior-point method: an interior point (barrier without "
+                                  "crossover) has to come from another backend, e.g. solver='HGS+HIP'")
 
     def reset_model(self) -> None:
         self._res = None
@@ -195,9 +265,18 @@ class SplitCaller(SolverCaller):
     def add_warm_start_solution(self, start_solution):
         self._spx.add_warm_start_solution(start_solution)
 
+    @property
+    def crash_from_warm_start(self):
+        return getattr(self._spx, "crash_from_warm_start", False)
+
     def run_barrier(self):
-        self._active = self._bar
-        self._bar.run_barrier()
+        # vertex wanted: a simplex backend that can start from the interior point it is handed takes it
+        if self.crash_from_warm_start:
+            self._active = self._spx
+            self._spx.run_barrier()
+        else:
+            self._active = self._bar
+            self._bar.run_barrier()
 
     def run_barrier_no_crossover(self):
         self._active = self._bar

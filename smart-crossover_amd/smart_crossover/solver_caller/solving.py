@@ -68,6 +68,10 @@ def solve_problem(solver_caller: SolverCaller, method: str, settings: SolverSett
          "network_simplex": solver_caller.run_network_simplex, "primal_simplex": solver_caller.run_primal_simplex,
          "dual_simplex": solver_caller.run_dual_simplex}[method]()
     elif method == "barrier":
+        # extension for backends outside the reference's three: one that builds its vertex from the interior
+        # point (solver_caller/hip.py) is handed the warm start; the reference's backends never are (Q6)
+        if warm_start_solution is not None and getattr(solver_caller, "crash_from_warm_start", False):
+            solver_caller.add_warm_start_solution(warm_start_solution)
         if settings.crossover == "on":
             solver_caller.run_barrier()
         else:

@@ -140,3 +140,42 @@ def test_config3_network_crossover_device_resident_equals_host_solver(method):
         assert X.min() >= -1e-12 and np.count_nonzero(X > 1e-13) <= S + D - 1
         costs[solver] = float((X * inst.M).sum())
     assert costs["HIP"] == pytest.approx(costs["HGS"], rel=1e-9)
+
+
+def test_config2_perturbation_crossover_end_to_end_on_the_device():
+    """BASELINE config 2 (2e4 x 1e5, 2e6 entries) through the crossover proper, all on the GPU: from the
+    interior point (x, y) to a vertex of the perturbed sub-problem with its basis -- get_perturb_problem, then
+    the re-solve of the 2e4-row sub-LP by the device simplex (crash basis from the interior point, dense
+    inverse of 3.2 GB), then the gap test (reference lp_methods/algorithms.py:45-67).  HiGHS-independent
+    certificates: primal and dual feasibility by basis status at the reference's tolerances, |B| = m, and the
+    gap against the interior objective."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.config2()
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    with redirect_stdout(io.StringIO()):
+        mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+        sub = mgr.lp_sub
+        out = solve_lp(sub, "HIP", "barrier", SolverSettings(presolve="on", log_console=0),
+                       warm_start_solution=(mgr.get_subx(inst.x), inst.y))
+    assert out.status == "OPTIMAL"
+    m, n = sub.A.shape
+    x, y, vb, cb = out.x, out.y, out.basis.vbasis, out.basis.cbasis
+    tol = 1e-6
+    s_p = sub.b - sub.A @ x
+    lt = np.asarray(sub.sense) == "<"
+    assert np.all(np.abs(s_p[~lt]) <= tol) and np.all(s_p[lt] >= -tol)
+    assert np.all(x >= sub.l - tol) and np.all(x <= sub.u + tol)
+    rc = sub.c - sub.A.T @ y
+    assert np.all(rc[vb == -1] >= -tol) and np.all(rc[vb == -2] <= tol) and np.all(np.abs(rc[vb == 0]) <= tol)
+    assert np.all(y[lt & (cb == -1)] <= tol) and np.all(np.abs(y[cb == 0]) <= tol)
+    assert int(np.count_nonzero(vb == 0) + np.count_nonzero(cb == 0)) == m
+    # the vertex is (numerically) optimal for the original objective too: the reference's own acceptance test
+    x_full = mgr.get_orix(x)
+    obj_interior = float(lp.c @ inst.x)
+    gap = abs(float(lp.c @ x_full) - obj_interior) / (abs(float(lp.c @ x_full)) + abs(obj_interior) + 1)
+    assert gap < 1e-5

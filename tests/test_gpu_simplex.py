@@ -164,8 +164,9 @@ def test_infeasible_and_unbounded():
                     np.full(2, np.inf), np.array(["<"]))
     out = solve_lp(unb, "HIP", "default", settings())
     assert out.status == "UNBOUNDED"
-    with pytest.raises(NotImplementedError):
-        solve_lp(bad, "HIP", "barrier", settings())
+    from smart_crossover.solver_caller.caller import SolverSettings
+    with pytest.raises(NotImplementedError):      # no interior-point method: barrier without crossover has no answer
+        solve_lp(bad, "HIP", "barrier", SolverSettings(log_console=0, crossover="off"))
 
 
 def test_mcf_and_degenerate_assignment():
@@ -278,3 +279,79 @@ def test_session_reuses_the_inverse_across_column_generation_rounds():
     assert r4.status == 0 and r4.warm_start_used in (0, 1) and r4.obj == pytest.approx(want, rel=1e-9)
     sess.free()
     ctx.close()
+
+
+def test_infeasible_warm_basis_is_repaired_by_phase_one_not_dropped():
+    """A warm basis whose basic solution violates bounds -- structurals as well as logicals -- is kept and
+    driven to feasibility by phase 1 (the reference's solvers repair warm bases; lp_manager.py:79-89 hands
+    over bases whose fixed-low columns are all at -1)."""
+    from smart_crossover.output import Basis
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(200, 700, 5, seed=41, stratified=False, frac_upper=0.4)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    rng = np.random.default_rng(5)
+    vb = np.full(700, -1)
+    vb[rng.choice(700, size=200, replace=False)] = 0           # an arbitrary, almost surely infeasible basis
+    vb[(vb == -1) & np.isfinite(inst.u) & (rng.random(700) < 0.3)] = -2
+    cb = np.full(200, -1)
+    out = solve_lp(lp, "HIP", "primal_simplex", settings(), warm_start_basis=Basis(vb, cb))
+    check_vertex(lp, out, ref.obj_val)
+
+
+def test_reinversion_from_the_basis_columns_keeps_the_solve_on_course():
+    """spx_force_reinvert rebuilds the inverse from the columns of the current basis at every check
+    (every 64 pivots here); the solve must still end at the optimum with a point that satisfies A x + s = b."""
+    from smart_crossover.hip.device import default_context
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(300, 1200, 5, seed=19, stratified=False, frac_upper=0.3)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    ctx = default_context()
+    ctx.set_option("spx_check", 64)
+    ctx.set_option("spx_force_reinvert", 1)
+    try:
+        out = solve_lp(lp, "HIP", "primal_simplex", settings())
+    finally:
+        ctx.set_option("spx_check", 2048)
+        ctx.set_option("spx_force_reinvert", 0)
+    check_vertex(lp, out, ref.obj_val)
+    assert out.iter_count > 64
+
+
+def test_barrier_with_crossover_on_the_device_starts_from_the_interior_point():
+    """method='barrier' (crossover on) with solver 'HIP': crash basis from the interior point handed over as
+    warm start + primal simplex (the substitute for the reference's barrier + crossover re-solve,
+    lp_methods/algorithms.py:50-54); without crossover it has no answer and says so."""
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(250, 900, 5, seed=23, stratified=False, frac_upper=0.3)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    cold = solve_lp(lp, "HIP", "barrier", SolverSettings(log_console=0))
+    check_vertex(lp, cold, ref.obj_val)
+    # a point close to the optimal vertex: far fewer pivots than from the slack basis
+    x_near = 0.98 * ref.x + 0.02 * np.clip(ref.x + 0.1, lp.l, np.where(np.isfinite(lp.u), lp.u, ref.x + 1.0))
+    warm = solve_lp(lp, "HIP", "barrier", SolverSettings(log_console=0), warm_start_solution=(x_near, ref.y))
+    check_vertex(lp, warm, ref.obj_val)
+    assert warm.iter_count < cold.iter_count
+    with pytest.raises(NotImplementedError):
+        solve_lp(lp, "HIP", "barrier", SolverSettings(log_console=0, crossover="off"))
+
+
+def test_perturbation_crossover_re_solves_on_the_device():
+    """run_perturb_algorithm with 'HGS+HIP': the initial barrier solve (the input of the crossover) in HiGHS,
+    the perturbed sub-problem and the final warm simplex on the device."""
+    from smart_crossover.lp_methods.algorithms import run_perturb_algorithm
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(600, 3000, 6, seed=61, stratified=False, frac_upper=0.3)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        out = run_perturb_algorithm(lp, "HGS+HIP", 1e-10, 1e-6)
+    text = buf.getvalue()
+    assert out.status == "OPTIMAL"
+    assert "Getting and solving a perturb subproblem" in text
+    if "A primal optimal BFS is found" not in text:
+        check_vertex(lp, out, ref.obj_val)
