@@ -19,9 +19,11 @@ Workload (weak scaling): rank r owns column block r (m x n_block, CSC) and row b
 256 MiB Infinity Cache, so HBM GB/s is honest).  ``--workload c2`` runs configs[1]
 (2e4 x 1e5, cache resident).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` for
-sx_score_columns (HIP-event timed inside the timed region) and ``cpu_baseline`` (the numpy/scipy
-oracle timed on the host cores, rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` for the walk that takes
+the largest share of the step (K1, K2 and K10 are all timed with HIP events inside the timed region and
+reported under ``kernels``), ``roofline_uniform`` (the same three walks on the no-locality variant of the
+workload, N = 1 only), ``cpu_baseline`` (the numpy/scipy oracle timed on the host cores, rank 0, N = 1 only)
+and ``crossover`` (wall times of whole crossovers through the drop-in API).
 """
 import argparse
 import json
@@ -90,6 +92,97 @@ def crossover_host_path(cpu_budget_s: float):
             "index_sets_and_subproblem_match_cpu": True}
 
 
+def crossover_lp_end_to_end(highs_limit_s: float):
+    """BASELINE metric 'crossover wall-time (ms)', LP case, config 2 (2e4 x 1e5): from the interior point (x, y)
+    in host memory to the optimal vertex of the perturbed sub-problem and its basis in host memory, i.e.
+    get_perturb_problem + the re-solve (reference lp_methods/algorithms.py:45-61) + the gap test (:63), all on the
+    GPU (solver 'HIP': crossover from the interior point by the device simplex).  Beside it the CPU path: the same
+    host arithmetic by the numpy/scipy oracle plus the re-solve of the same sub-problem by HiGHS (the stand-in
+    for Gurobi), stopped at ``highs_limit_s`` seconds so that the default run stays short -- a limit that is hit
+    is reported as such, not as a solve time."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.config2()
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+        t1 = time.perf_counter()
+        out = solve_lp(mgr.lp_sub, "HIP", "barrier", SolverSettings(presolve="on", log_console=0),
+                       warm_start_solution=(mgr.get_subx(inst.x), inst.y))
+        ok = alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x))
+    t2 = time.perf_counter()
+    if out.status != "OPTIMAL" or not ok:
+        raise SystemExit("bench: the device crossover of config 2 did not reach an optimal vertex")
+    rec = {"workload": "c2: 2e4 x 1e5, 2e6 nnz; interior point -> optimal vertex + basis of the perturbed 2e4 x 2e4 "
+                       "sub-problem, host memory to host memory",
+           "gpu_ms": (t2 - t0) * 1e3, "gpu_get_perturb_problem_ms": (t1 - t0) * 1e3, "gpu_resolve_ms": (t2 - t1) * 1e3,
+           "simplex_pivots": int(out.iter_count), "gap_test_passed": True}
+    if highs_limit_s > 0:
+        t0 = time.perf_counter()
+        status = "TIME_LIMIT"
+        try:
+            with redirect_stdout(io.StringIO()):
+                ref = solve_lp(mgr.lp_sub, "HGS", "default",
+                               SolverSettings(presolve="on", log_console=0, timeLimit=int(highs_limit_s)))
+            status = ref.status
+        except Exception as exc:                # the stand-in raises when it stops without a solution
+            status = f"{type(exc).__name__}"
+        secs = time.perf_counter() - t0
+        solved = status == "OPTIMAL"
+        rec.update({"cpu_kind": "HiGHS (scipy's bundled build, all host cores it chooses to use) on the same sub-problem; "
+                                "the reference would call Gurobi here",
+                    "cpu_resolve_status": status, "cpu_resolve_seconds": secs,
+                    "cpu_resolve_time_limit_s": highs_limit_s,
+                    "speedup_resolve": (secs * 1e3 / rec["gpu_resolve_ms"]) if solved else None,
+                    "speedup_resolve_at_least": None if solved else secs * 1e3 / rec["gpu_resolve_ms"]})
+    return rec
+
+
+def crossover_lp_c5():
+    """get_perturb_problem at full config-5 size (1e6 x 1e7, 8e7 entries) through the drop-in API: scipy CSR +
+    numpy vectors in host memory -> restricted sub-problem in host memory (uploads, 1000 CG iterations = 2000
+    sparse products, compaction, downloads)."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods.algorithms import get_perturb_problem
+    sh = workloads.lp_shard(0, 1)
+    rng = np.random.default_rng(11)
+    sense = np.where(rng.random(sh.m) < 0.5, "<", "=")
+    lp = GeneralLP(sh.row_block, sh.b, sh.c, sh.l, sh.u, sense)
+    times = []
+    mgr = None
+    for rep in range(2):
+        fresh = GeneralLP(lp.A, lp.b.copy(), lp.c.copy(), lp.l.copy(), lp.u.copy(), lp.sense.copy()) if rep else lp
+        t0 = time.perf_counter()
+        with redirect_stdout(io.StringIO()):
+            mgr = get_perturb_problem(fresh, sh.x, sh.y, 1e-3, 1e-3, False)
+        times.append((time.perf_counter() - t0) * 1e3)
+    info = getattr(mgr, "perturb_info", {}) or {}
+    return {"workload": "c5: 1e6 x 1e7, 8e7 nnz, get_perturb_problem (is_feas=False), host memory to host memory",
+            "gpu_ms_first_call": times[0], "gpu_ms": times[1], "cg_iters": int(info.get("cg_iters", 0)),
+            "fixed_columns": int(mgr.get_num_fixed_variables()), "fixed_rows": int(mgr.get_num_fixed_constraints()),
+            "sub_problem_shape": list(mgr.lp_sub.A.shape),
+            "cpu_note": "the reference cannot run this size (explicit Y Y^T); its matrix-free restatement needs ~0.4 s per "
+                        "CG iteration on one core"}
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources: a PMC traffic figure is only reused for the build it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "smart-crossover_amd", "csrc", "*"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def crossover_network():
     """BASELINE metric, part 'crossover wall-time (ms)', network case: the whole ``network_crossover`` call
     (TNET) on config 3 -- OT on the 28 x 28 grid, 784 x 784, 614,656 arcs -- from the inexact plan in host
@@ -137,7 +230,10 @@ def main():
                     help="row structure of the synthetic LP (default: staircase = netlib-style for c5, uniform for c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
-    ap.add_argument("--no-crossover", action="store_true", help="skip the config-2 crossover host-path timing")
+    ap.add_argument("--no-crossover", action="store_true", help="skip the whole-crossover timings")
+    ap.add_argument("--no-uniform", action="store_true", help="skip the no-locality (uniform) record")
+    ap.add_argument("--highs-seconds", type=float, default=120.0,
+                    help="time limit of the HiGHS re-solve timed beside the device crossover of config 2 (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -273,30 +369,82 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    k1_ms = [ctx.marker_elapsed(5 * i, 5 * i + 1) for i in range(n_marked)]
-    k2_ms = float(np.mean([ctx.marker_elapsed(5 * i + 1, 5 * i + 2) for i in range(n_marked)]))
-    k10_ms = float(np.mean([ctx.marker_elapsed(5 * i + 3, 5 * i + 4) for i in range(n_marked)]))
-    k2_bytes = 12 * sh.row_block.nnz + 8 * n_tot + 33 * m_loc
-    # K10 as the step calls it (rc_out = None): entries 12 nnz, colptr 8 n, c 8 n, vbasis n, y 8 m -- no 8-byte store
-    k10_bytes = 12 * sh.col_block.nnz + 17 * n_loc + 8 * m
-    k1_avg_s = float(np.mean(k1_ms)) / 1e3
+    k1_list = [ctx.marker_elapsed(5 * i, 5 * i + 1) for i in range(n_marked)]
+    k2_list = [ctx.marker_elapsed(5 * i + 1, 5 * i + 2) for i in range(n_marked)]
+    k10_list = [ctx.marker_elapsed(5 * i + 3, 5 * i + 4) for i in range(n_marked)]
     nnz_loc = sh.col_block.nnz
-    k1_bytes = 12 * nnz_loc + 49 * n_loc + 8 * m        # K1 algorithmic bytes
-    achieved = k1_bytes / k1_avg_s / 1e9
 
-    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the
-    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/rNN/),
-    # corrected as MI355X_MICROARCH.md prescribes; null when no pass matches the workload
+    def kernel_records(k1, k2, k10, col_nnz, row_nnz):
+        """Algorithmic bytes over the HIP-event time of each of the three walks."""
+        algo = {
+            # entries 12 B, colptr + c, x, l, u in (40 B), s_d + code out (9 B) per column, y once
+            "k_score_columns": 12 * col_nnz + 49 * n_loc + 8 * m,
+            # entries 12 B, x once, rowptr + b + y in (24 B) and s_p + flag out (9 B) per row
+            "k_score_rows": 12 * row_nnz + 8 * n_tot + 33 * m_loc,
+            # as the step calls it (rc_out = None): entries, colptr + c + vbasis (17 B per column), y once; no store
+            "k_price": 12 * col_nnz + 17 * n_loc + 8 * m,
+        }
+        recs = {}
+        for name, ms in (("k_score_columns", k1), ("k_score_rows", k2), ("k_price", k10)):
+            avg = float(np.mean(ms))
+            recs[name] = {"avg_kernel_ms": avg, "min_kernel_ms": float(np.min(ms)), "algorithmic_bytes": int(algo[name]),
+                          "achieved_GBps": algo[name] / avg / 1e6, "frac_of_hbm_peak": algo[name] / avg / 1e6 / HBM_PEAK_GBS}
+        return recs
+
+    kernels = kernel_records(k1_list, k2_list, k10_list, nnz_loc, sh.row_block.nnz)
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_kernel_ms"])
+
+    # HBM bytes per launch of the dominant kernel from the PMC counters: they cannot be read from inside this
+    # process, so the figure comes from a committed rocprofv3 --pmc pass of this same command
+    # (profiles/rNN/kernel_traffic.json, corrected as MI355X_MICROARCH.md prescribes) and is only used when that
+    # pass was taken on these very kernel sources (hash) and this workload; null otherwise
     traffic = None
     try:
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k_score_columns_traffic.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "kernel_traffic.json")), reverse=True):
             rec = json.load(open(path))
-            if rec.get("workload") == f"{args.workload}/{structure}":
-                traffic = rec["traffic_bytes_per_launch"]
+            if rec.get("workload") == f"{args.workload}/{structure}" and rec.get("source_hash") == source_hash():
+                traffic = rec.get("traffic_bytes_per_launch", {}).get(dominant)
                 break
     except Exception:
         traffic = None
+
+    # ---- the same three walks on the no-locality variant of the workload (uniformly random rows): the LDS
+    # windows of K1 / K10 and the column-blocked rows of K2 find nothing to hold on to there
+    uniform = None
+    if rank == 0 and world == 1 and args.workload == "c5" and structure != "uniform" and not args.no_uniform:
+        for a in (dC, dR):
+            a.free()
+        shu = workloads.lp_shard(0, 1, m=m, n_block=n_block, k=k, seed=5, structure="uniform")
+        uC, uR = ctx.column_shard(shu.col_block), ctx.row_shard(shu.row_block)
+        u_y, u_x = ctx.to_device(shu.y), ctx.to_device(shu.x)
+        u_c, u_l, u_u, u_b = (ctx.to_device(v) for v in (shu.c, shu.l, shu.u, shu.b))
+        # outputs of their own: the results of the timed run above are still to be checked and reported
+        o_sd, o_code = ctx.empty(n_loc, np.float64), ctx.empty(n_loc, np.uint8)
+        o_sp, o_flag = ctx.empty(m_loc, np.float64), ctx.empty(m_loc, np.uint8)
+        o_price = ctx.empty(24, np.uint8)
+        t1, t2, t10 = [], [], []
+        for i in range(2 + 5):
+            ctx.marker(0)
+            ctx.score_columns(uC, u_y, u_c, u_x, u_l, u_u, gamma, o_sd, o_code)
+            ctx.marker(1)
+            ctx.score_rows(uR, u_x, u_b, u_y, gamma, o_sp, o_flag)
+            ctx.marker(2)
+            ctx.price(uC, u_y, u_c, vb, 1e-6, None, o_price)
+            ctx.marker(3)
+            ctx.sync()
+            if i >= 2:
+                t1.append(ctx.marker_elapsed(0, 1))
+                t2.append(ctx.marker_elapsed(1, 2))
+                t10.append(ctx.marker_elapsed(2, 3))
+        ku = kernel_records(t1, t2, t10, shu.col_block.nnz, shu.row_block.nnz)
+        dom_u = max(ku, key=lambda kk: ku[kk]["avg_kernel_ms"])
+        uniform = {"workload": "c5 with uniformly random rows (8 strata per column): no locality for the gathers",
+                   "kernel": dom_u, "bound": "hbm", "achieved": ku[dom_u]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": ku[dom_u]["frac_of_hbm_peak"], "traffic": None, "kernels": ku,
+                   "row_layout": "column-blocked" if uR.rowblock() is not None else "plain walk (auto rule)"}
+        for a in (uC, uR):
+            a.free()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_loc / (elapsed / args.steps)
@@ -335,8 +483,13 @@ def main():
 
     crossover = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_crossover:
-        crossover = crossover_host_path(args.cpu_seconds)
-        crossover = {"lp_c2_host_path": crossover, "network_c3": crossover_network()}
+        if uniform is None:             # free the resident c5 shard before the crossovers allocate theirs
+            for a in (dC, dR):
+                a.free()
+        crossover = {"lp_c2_host_path": crossover_host_path(args.cpu_seconds),
+                     "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
+                     "lp_c5_get_perturb_problem": crossover_lp_c5(),
+                     "network_c3": crossover_network()}
 
     if rank == 0:
         out = {
@@ -347,19 +500,14 @@ def main():
                        "nnz_per_gpu": int(nnz_loc), "step": "K1 score_columns + K2 score_rows + 3x select_indices + K10 price"
                                                             + (" + all_gather(48 B: pricing record + 3 set sizes)" if world > 1 else ""),
                        "parallelism": f"column/row blocks over {world} GPU(s)"},
-            "roofline": {"kernel": "k_score_columns", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": int(k1_bytes), "avg_kernel_ms": k1_avg_s * 1e3,
-                         "min_kernel_ms": float(np.min(k1_ms))},
-            # the other two walks of the step (HIP events, same run); K2 is bound by L1<->L2 line fills of its
-            # x gathers, not by HBM, its HBM fraction is reported for completeness
-            "other_kernels": {
-                "k_score_rows": {"avg_kernel_ms": k2_ms, "algorithmic_bytes": int(k2_bytes),
-                                 "achieved_GBps": k2_bytes / k2_ms / 1e6, "frac_of_hbm_peak": k2_bytes / k2_ms / 1e6 / HBM_PEAK_GBS,
-                                 "bound": "l1-l2 fabric (gather line fills)"},
-                "k_price": {"avg_kernel_ms": k10_ms, "algorithmic_bytes": int(k10_bytes),
-                            "achieved_GBps": k10_bytes / k10_ms / 1e6, "frac_of_hbm_peak": k10_bytes / k10_ms / 1e6 / HBM_PEAK_GBS,
-                            "bound": "hbm"}},
+            # the walk with the largest share of the step; all three under "kernels" (HIP events, same run)
+            "roofline": {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBps"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dominant]["frac_of_hbm_peak"],
+                         "traffic": traffic, "algorithmic_bytes": kernels[dominant]["algorithmic_bytes"],
+                         "avg_kernel_ms": kernels[dominant]["avg_kernel_ms"],
+                         "min_kernel_ms": kernels[dominant]["min_kernel_ms"]},
+            "kernels": kernels,
+            "roofline_uniform": uniform,
             "cpu_baseline": cpu,
             "crossover": crossover,
             "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),

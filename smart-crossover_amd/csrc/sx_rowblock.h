@@ -9,7 +9,7 @@
 // a window ("windowed"), or a run of consecutive sparse blocks ("direct") -- and inside a cell by
 // (row, stored order).  A workgroup walks the cells of its super-tile in ascending column order, loads
 // the x block of a windowed cell into LDS with coalesced loads and gathers from LDS; lane t keeps the
-// running sum of row t in a register.  A row whose columns do not descend meets its entries in stored
+// running sums of its rows (t, t + RB_TW, ...) in registers.  A row whose columns do not descend meets its entries in stored
 // order, so the sums are the sequential sums of the plain walk, bit for bit (a matrix with a row whose
 // columns descend somewhere stays on the plain walk: the builder refuses it).
 //
@@ -54,7 +54,9 @@ struct sx_rb_supertile {
 constexpr int32_t RB_NO_WINDOW = -(1 << 30);
 
 // parameters of the layout the library builds (measured on MI355X, profiles/r02/rb_bench_*.txt)
-constexpr int RB_R = 512;              // rows per super-tile = lanes per workgroup of the walk
+constexpr int RB_TW = 512;             // lanes per workgroup of the walk
+constexpr int RB_RPL = 1;              // rows per lane: lane t owns rows t, t + RB_TW, ... of its super-tile
+constexpr int RB_R = RB_TW * RB_RPL;   // rows per super-tile
 constexpr int RB_CWIN = 4096;          // columns per block = doubles of the LDS window
 constexpr int RB_CHUNK = 2048;         // entries staged per step
 constexpr int RB_DENSE_MIN = 512;      // a block with at least this many entries gets a window

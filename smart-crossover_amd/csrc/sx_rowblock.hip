@@ -3,7 +3,8 @@
 // (lp_methods/algorithms.py:183-187).  Same sums, same roundings as the plain walk of sx_segwalk.h;
 // built with -ffp-contract=off.
 //
-// One workgroup of RB_R lanes owns a super-tile (one row per lane) and steps through its chunks.  Step k:
+// One workgroup of RB_TW lanes owns a super-tile (RB_RPL rows per lane: the wider the super-tile, the fewer
+// times an x window is loaded) and steps through its chunks.  Step k:
 //   issue    if chunk k+1 opens a new cell: its row starts and its x window (registers); then the entries of
 //            chunk k+1 (registers) -- the youngest loads, which the waits of this step leave in flight
 //   stage    rounded products of chunk k -> LDS; the operand comes from the LDS window of the cell, or from
@@ -21,7 +22,6 @@
 
 namespace {
 
-constexpr int RB_TW = RB_R;                     // lanes per workgroup
 constexpr int RB_NQ = RB_CHUNK / (RB_TW * 4);   // 16-byte index loads per lane and chunk
 constexpr int RB_NW = RB_CWIN / (RB_TW * 2);    // 16-byte window pieces per lane
 constexpr int RB_NT = 2;                        // cache policy of the entry stream: non-temporal
@@ -152,14 +152,16 @@ struct RbLayout {
     int64_t nst;
 };
 
-// sum of row S.row0 + tid over the super-tile (0 for lanes beyond its rows); all lanes of the workgroup call it
-__device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_rb_supertile &S, const double *__restrict__ x,
-                                                   int64_t ncols, RbLds &lds) {
+// acc[r] = sum of row S.row0 + tid + r * RB_TW over the super-tile (0 for rows beyond its end); all lanes of the
+// workgroup call it
+__device__ __forceinline__ void rb_supertile_sum(const RbLayout &L, const sx_rb_supertile &S, const double *__restrict__ x,
+                                                 int64_t ncols, RbLds &lds, double (&acc)[RB_RPL]) {
     const int tid = threadIdx.x;
     const int *ck = reinterpret_cast<const int *>(L.chunks + S.chunk0);
     const int n = S.nchunks;
-    double acc = 0.0;
-    if (n <= 0) return acc;
+#pragma unroll
+    for (int r = 0; r < RB_RPL; ++r) acc[r] = 0.0;
+    if (n <= 0) return;
     int g = 0;
     auto load_tab = [&]() {
         for (int i = tid; i < RB_TABN * 8; i += RB_TW) {
@@ -168,11 +170,15 @@ __device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_r
             lds.tab[i] = ck[static_cast<int64_t>(rec) * 8 + (i & 7)];
         }
     };
-    auto load_rs = [&](int (&rs)[2], const sx_rb_chunk &c) {
+    auto load_rs = [&](int (&rs)[RB_RPL][2], const sx_rb_chunk &c) {
         const __amdgpu_buffer_rsrc_t rr = rb_rsrc(L.rowstart + static_cast<int64_t>(c.cell) * RB_RS_STRIDE, RB_RS_STRIDE * 2u);
-        const int k0 = tid < S.nrows ? tid : S.nrows, k1 = tid + 1 < S.nrows ? tid + 1 : S.nrows;
-        rs[0] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k0 * 2, 0, 0));
-        rs[1] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k1 * 2, 0, 0));
+#pragma unroll
+        for (int r = 0; r < RB_RPL; ++r) {
+            const int row = tid + r * RB_TW;
+            const int k0 = row < S.nrows ? row : S.nrows, k1 = row + 1 < S.nrows ? row + 1 : S.nrows;
+            rs[r][0] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k0 * 2, 0, 0));
+            rs[r][1] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rr, k1 * 2, 0, 0));
+        }
     };
     auto load_win = [&](sx_v2d (&wreg)[RB_NW], const sx_rb_chunk &c) {
         const int64_t room = ncols - c.col0;
@@ -185,7 +191,7 @@ __device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_r
 #pragma unroll
         for (int w = 0; w < RB_NW; ++w) *reinterpret_cast<sx_v2d *>(lds.win + w * RB_TW * 2 + tid * 2) = wreg[w];
     };
-    int rs[2], rs_next[2];
+    int rs[RB_RPL][2], rs_next[RB_RPL][2];
     RbEntries E[2];
     sx_v2d wreg[RB_NW];
     __syncthreads(); // the previous super-tile of a grid-stride caller is done with the LDS
@@ -207,11 +213,15 @@ __device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_r
         if (has_next) rb_load(Enext, cn, L.idx, L.val);
         rb_stage(Ecur, c, lds.win, x, lds.prod);
         __syncthreads();
-        rb_consume(acc, rs[0], rs[1], c.base, c.ne, lds.prod);
+#pragma unroll
+        for (int r = 0; r < RB_RPL; ++r) rb_consume(acc[r], rs[r][0], rs[r][1], c.base, c.ne, lds.prod);
         if (new_win) store_win(wreg);
         if (open) {
-            rs[0] = rs_next[0];
-            rs[1] = rs_next[1];
+#pragma unroll
+            for (int r = 0; r < RB_RPL; ++r) {
+                rs[r][0] = rs_next[r][0];
+                rs[r][1] = rs_next[r][1];
+            }
         }
         if (has_next && k + 1 == g + RB_TAB) { // next group of records
             __syncthreads();
@@ -225,7 +235,6 @@ __device__ __forceinline__ double rb_supertile_sum(const RbLayout &L, const sx_r
         step(E[0], E[1], k);
         if (k + 1 < n) step(E[1], E[0], k + 1);
     }
-    return acc;
 }
 
 // ------------------------------------------------------------------------------------- K2
@@ -237,12 +246,17 @@ __global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_score_rows(RbLayout L, in
     const int64_t tile = sx_tile_of_block(blockIdx.x, L.nst, swizzle);
     if (tile >= L.nst) return;
     const sx_rb_supertile S = L.st[tile];
-    const double sum = rb_supertile_sum(L, S, x, ncols, lds);
-    if (static_cast<int>(threadIdx.x) < S.nrows) {
-        const int64_t row = S.row0 + threadIdx.x;
-        const double sp = b[row] - sum;
-        if (s_p) s_p[row] = sp;
-        if (flag) flag[row] = (sp < (gamma_dual * (-y[row]))) ? 1 : 0;
+    double sum[RB_RPL];
+    rb_supertile_sum(L, S, x, ncols, lds, sum);
+#pragma unroll
+    for (int r = 0; r < RB_RPL; ++r) {
+        const int lr = threadIdx.x + r * RB_TW;
+        if (lr < S.nrows) {
+            const int64_t row = S.row0 + lr;
+            const double sp = b[row] - sum[r];
+            if (s_p) s_p[row] = sp;
+            if (flag) flag[row] = (sp < (gamma_dual * (-y[row]))) ? 1 : 0;
+        }
     }
 }
 
@@ -276,17 +290,23 @@ __global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swiz
     double dot = 0.0;
     for (; t < t_end; t += t_step) {
         const sx_rb_supertile S = L.st[t];
-        double qi = rb_supertile_sum(L, S, w, ncols, lds);
-        if (static_cast<int>(threadIdx.x) < S.nrows) {
-            const int64_t row = S.row0 + threadIdx.x;
-            if (p) {
-                const double s = xs[row], pi = p[row];
-                qi = qi + (s * s) * pi;
-                dot += pi * qi;
-            } else {
-                dot += qi * qi;
+        double sum[RB_RPL];
+        rb_supertile_sum(L, S, w, ncols, lds, sum);
+#pragma unroll
+        for (int r = 0; r < RB_RPL; ++r) {
+            const int lr = threadIdx.x + r * RB_TW;
+            if (lr < S.nrows) {
+                const int64_t row = S.row0 + lr;
+                double qi = sum[r];
+                if (p) {
+                    const double s = xs[row], pi = p[row];
+                    qi = qi + (s * s) * pi;
+                    dot += pi * qi;
+                } else {
+                    dot += qi * qi;
+                }
+                q[row] = qi;
             }
-            q[row] = qi;
         }
     }
     // fixed-order block sum

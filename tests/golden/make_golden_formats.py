@@ -5,7 +5,7 @@ make_opt_transport_instances) on small inputs written here.  Build-container onl
 ``idx2numpy`` is not installed; mnist2ot.py imports it at module top, so an empty placeholder module of
 that name lets the import resolve -- its reader is not used (the images below are generated arrays).
 
-Outputs (data only): g6_dimacs_small.min (input text), g6_formats.npz.
+Outputs (data only): g6_dimacs_small.min (input text), g6_formats.npz, g6_summaries.json.
 Usage:  python tests/golden/make_golden_formats.py
 """
 import importlib.util
@@ -78,6 +78,53 @@ def main():
         ot0_s=ots[0].s, ot0_d=ots[0].d, ot0_M=ots[0].M, ot1_s=ots[1].s, ot1_d=ots[1].d, ot1_M=ots[1].M,
         ot_names=np.array([o.name for o in ots]))
     print("wrote g6_dimacs_small.min, g6_formats.npz;", A.shape, len(ots), "OT instances")
+    summaries()
+
+
+def summaries():
+    """Summary statistics of the reference's analysis (visualization.py:181-195 called as is; :415 is an inline
+    pandas expression, evaluated here on a small frame exactly as written there)."""
+    import json
+    import pandas as pd
+    # visualization.py imports filehandling.py, which imports gurobipy and evaluates get_project_root() at import
+    # time: an empty placeholder module lets the import statement resolve (no solver behaviour is provided), and
+    # the import is made from a directory named like the project, which is all that function looks for
+    for _name in ("gurobipy", "cplex", "mosek", "mosek.fusion"):
+        _m = types.ModuleType(_name)
+        for _a in ("GRB", "Model", "Cplex"):
+            setattr(_m, _a, type(_a, (), {}))
+        sys.modules.setdefault(_name, _m)
+    import tempfile
+    _cwd = os.getcwd()
+    _tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(_tmp, "smart-crossover"))
+    os.chdir(os.path.join(_tmp, "smart-crossover"))
+    try:
+        import smart_crossover.visualization as viz
+    finally:
+        os.chdir(_cwd)
+    rng = np.random.default_rng(16)
+    ptime = rng.uniform(0.5, 400.0, 12)
+    cross = rng.uniform(0.5, 400.0, 12)
+    ptime[[2, 7]] = np.nan
+    cross[[5]] = np.nan
+    ptime[9], cross[9] = np.nan, np.nan
+    df = pd.DataFrame({"Ptime": ptime.copy(), "Crossover(ori)": cross.copy()})
+    with redirect_stdout(io.StringIO()) as text:
+        avg = viz.calculate_average_improvement_lp(df, "ptb")
+    names = [f"{g}_{k}" for g in ("goto", "netgen", "road") for k in range(4)]
+    net = pd.DataFrame({"grb_runtime": rng.uniform(0.0, 30.0, 12), "cnet_runtime": rng.uniform(0.0, 30.0, 12)}, index=names)
+    net["group"] = net.index.str.split("_").str[0]
+    grouped = net.groupby("group").agg(lambda x: np.exp(np.log(x + 0.01).mean())).round(2)
+    out = {"ptime": [None if np.isnan(v) else float(v) for v in ptime],
+           "crossover_ori": [None if np.isnan(v) else float(v) for v in cross],
+           "averages": [None if (isinstance(v, float) and np.isnan(v)) else float(v) for v in avg],
+           "printed": text.getvalue().strip(),
+           "net_rows": {n: {c: float(net.loc[n, c]) for c in ("grb_runtime", "cnet_runtime")} for n in names},
+           "net_grouped": {g: {c: float(grouped.loc[g, c]) for c in ("grb_runtime", "cnet_runtime")} for g in grouped.index}}
+    with open(os.path.join(HERE, "g6_summaries.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote g6_summaries.json")
 
 
 if __name__ == "__main__":

@@ -66,3 +66,29 @@ def test_ot_instances_match_reference_converter(g6):
         assert bits_equal(o.s, g6[f"ot{k}_s"]) and bits_equal(o.d, g6[f"ot{k}_d"])
         assert np.array_equal(o.M, g6[f"ot{k}_M"])
         assert abs(o.s.sum() - 1.0) < 1e-12 and abs(o.d.sum() - 1.0) < 1e-12
+
+
+def test_result_pickles_round_trip(tmp_path):
+    from smart_crossover import results as R
+    payload = {"goto_8_13a": {"grb_runtime": 1.5, "x": np.arange(4)}, "note": "anything picklable"}
+    R.write_results_to_pickle(payload, "ot/run1.pickle", root=str(tmp_path))
+    assert os.path.exists(tmp_path / "results" / "ot" / "run1.pickle")      # <root>/results/<path>, filehandling.py:103,109
+    back = R.read_results_from_pickle("ot/run1.pickle", root=str(tmp_path))
+    assert back["note"] == payload["note"] and np.array_equal(back["goto_8_13a"]["x"], payload["goto_8_13a"]["x"])
+    with pytest.raises(FileNotFoundError):
+        R.read_results_from_pickle("missing.pickle", root=str(tmp_path))
+
+
+def test_summary_statistics_match_the_reference_analysis():
+    """visualization.py:181-195 (called as is by the golden generator) and the grouped shifted geometric mean of
+    :415/:428 (the reference's inline pandas expression evaluated on the same rows)."""
+    import json
+    from smart_crossover import results as R
+    g = json.load(open(os.path.join(GOLDEN_DIR, "g6_summaries.json")))
+    nan = float("nan")
+    ptime = [nan if v is None else v for v in g["ptime"]]
+    cross = [nan if v is None else v for v in g["crossover_ori"]]
+    avg, avg_solver, avg_par, improved = R.average_improvement_lp(ptime, cross)
+    assert (avg, avg_solver, avg_par) == pytest.approx(tuple(g["averages"]), rel=1e-12)
+    assert g["printed"] == f"Number of improved problems: {improved}"
+    assert R.grouped_geometric_mean(g["net_rows"]) == g["net_grouped"]
