@@ -363,6 +363,17 @@ int sx_sinkhorn_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *a, const do
                     double reg, int64_t max_iter, double stop_thr, double *plan, double *u_out, double *v_out,
                     sx_sinkhorn_result *result);
 
+/* The same for B <= 16 instance pairs that share the cost matrix M (the reference's driver runs ten MNIST
+ * image pairs over one 28 x 28 grid one after the other, scripts/run_network_crossover.py:95-101): a[B*S],
+ * b[B*D] instance-major, a grid point an instance does not use carries mass 0 (IEEE arithmetic takes it out:
+ * the instance sees exactly the problem on its own support).  With the scaling vectors side by side K^T U and
+ * K V are dense (D x S)(S x B) / (S x D)(D x B) products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64);
+ * instances stop independently.  Outputs (device, any may be NULL): plans[B*S*D], u_out[B*S], v_out[B*D];
+ * results[B] is a HOST array.  Blocking. */
+int sx_sinkhorn_batch_dev(sx_ctx *ctx, int64_t S, int64_t D, int64_t B, const double *a, const double *b,
+                          const double *M, double reg, int64_t max_iter, double stop_thr, double *plans,
+                          double *u_out, double *v_out, sx_sinkhorn_result *results);
+
 /* Session: keeps the basis inverse of the last solve on the device so that the next solve of a
  * column-generation sequence (network_methods/algorithms.py:105-139: same rows, more columns, warm basis
  * = previous optimal basis) starts from it instead of re-installing the basis pivot by pivot.

@@ -266,6 +266,13 @@ class Context:
                                            int(max_iter), float(stop_thr), _ptr(plan), _ptr(u), _ptr(v), C.byref(res)))
         return res
 
+    def sinkhorn_batch(self, S, D, B, a, b, M, reg, max_iter=1000, stop_thr=1e-9, plans=None, u=None, v=None):
+        """B <= 16 entropic OT warm starts over one cost matrix (blocking); returns the B result records."""
+        res = (_l.SinkhornResult * int(B))()
+        _l.check(self._lib.sx_sinkhorn_batch_dev(self.handle, int(S), int(D), int(B), _ptr(a), _ptr(b), _ptr(M), float(reg),
+                                                 int(max_iter), float(stop_thr), _ptr(plans), _ptr(u), _ptr(v), res))
+        return list(res)
+
     def x_real(self, n, x, l, u, out, apply_floor: bool = True) -> None:
         _l.check(self._lib.sx_x_real_dev(self.handle, int(n), _ptr(x), _ptr(l), _ptr(u), int(bool(apply_floor)),
                                          _ptr(out)))

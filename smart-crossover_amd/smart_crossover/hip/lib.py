@@ -114,6 +114,8 @@ PROTOTYPES = {
                                         C.POINTER(SimplexResult)]),
     "sx_sinkhorn_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,
                                C.POINTER(SinkhornResult)]),
+    "sx_sinkhorn_batch_dev": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,
+                                     C.POINTER(SinkhornResult)]),
     "sx_simplex_session_create": (_int, [_vp, C.POINTER(_vp)]),
     "sx_simplex_session_destroy": (_int, [_vp]),
     "sx_simplex_solve_session_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp,

@@ -86,3 +86,58 @@ def test_bad_shapes_raise():
     from smart_crossover.sinkhorn import sinkhorn
     with pytest.raises(ValueError):
         sinkhorn(np.ones(3) / 3, np.ones(4) / 4, np.zeros((4, 3)), 1.0)
+
+
+def grid_instances(B, side, seed, sparsity=0.6):
+    """B "image pairs" on a side x side grid: random positive masses with a share of empty pixels, as MNIST images
+    have (scripts/mnist2ot.py keeps only the non-zero pixels of each image)."""
+    rng = np.random.default_rng(seed)
+    n = side * side
+    a = rng.random((B, n)) * (rng.random((B, n)) > sparsity)
+    b = rng.random((B, n)) * (rng.random((B, n)) > sparsity)
+    a[:, 0] += 0.1
+    b[:, -1] += 0.1
+    a /= a.sum(axis=1, keepdims=True)
+    b /= b.sum(axis=1, keepdims=True)
+    return a, b, workloads.grid_cost(side)
+
+
+@pytest.mark.parametrize("B,side,reg,iters", [(10, 28, 10.0, 1000), (3, 9, 2.0, 300), (16, 12, 4.0, 45), (1, 7, 1.5, 200)])
+def test_batched_warm_starts_match_the_algorithm_on_each_instances_own_support(B, side, reg, iters):
+    """Every instance of a batch must get what POT's algorithm gives on ITS support (the non-zero pixels of its
+    two images, which is what the reference feeds it): plans equal to 1e-9 relative on the support, exactly zero
+    off it, same iteration count up to one test interval."""
+    from smart_crossover.sinkhorn import sinkhorn_batch
+    a, b, M = grid_instances(B, side, seed=B + side)
+    plans, logs = sinkhorn_batch(a, b, M, reg, numItermax=iters, log=True)
+    assert plans.shape == (B, side * side, side * side)
+    for k in range(B):
+        sa, sb = np.flatnonzero(a[k]), np.flatnonzero(b[k])
+        want, wlog = OS.sinkhorn_knopp(a[k][sa], b[k][sb], M[np.ix_(sa, sb)], reg, numItermax=iters)
+        got = plans[k]
+        np.testing.assert_allclose(got[np.ix_(sa, sb)], want, rtol=RTOL, atol=1e-300)
+        off = got.copy()
+        off[np.ix_(sa, sb)] = 0.0
+        assert not off.any()                                   # no mass outside the instance's support
+        assert abs(logs[k]["niter"] - wlog["iters"]) <= 10
+        np.testing.assert_allclose(logs[k]["u"][sa], wlog["u"], rtol=RTOL)     # same start, same iterates
+        np.testing.assert_allclose(logs[k]["v"][sb], wlog["v"], rtol=RTOL)
+        assert not logs[k]["u"][np.setdiff1d(np.arange(a.shape[1]), sa)].any()      # unused pixels: scaling 0
+
+
+def test_batch_equals_the_single_instance_entry_point():
+    from smart_crossover.sinkhorn import sinkhorn, sinkhorn_batch
+    a, b, M = grid_instances(4, 10, seed=77, sparsity=0.0)       # full support: both entry points apply
+    plans = sinkhorn_batch(a, b, M, 3.0, numItermax=200)
+    for k in range(4):
+        np.testing.assert_allclose(plans[k], sinkhorn(a[k], b[k], M, 3.0, numItermax=200), rtol=RTOL, atol=1e-300)
+
+
+def test_more_than_sixteen_instances_run_in_several_batches():
+    from smart_crossover.sinkhorn import sinkhorn_batch
+    a, b, M = grid_instances(19, 6, seed=5, sparsity=0.3)
+    plans = sinkhorn_batch(a, b, M, 2.0, numItermax=100)
+    for k in (0, 15, 16, 18):
+        sa, sb = np.flatnonzero(a[k]), np.flatnonzero(b[k])
+        want, _ = OS.sinkhorn_knopp(a[k][sa], b[k][sb], M[np.ix_(sa, sb)], 2.0, numItermax=100)
+        np.testing.assert_allclose(plans[k][np.ix_(sa, sb)], want, rtol=RTOL, atol=1e-300)
