@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-crossover", action="store_true", help="skip the whole-crossover timings")
     ap.add_argument("--no-uniform", action="store_true", help="skip the no-locality (uniform) record")
+    ap.add_argument("--cg-iters", type=int, default=0,
+                    help="also time this many iterations of the column-sharded projector CG (one m-vector all-reduce per "
+                         "iteration over RCCL at N > 1): reported under 'sharded_cg', not part of the step")
     ap.add_argument("--highs-seconds", type=float, default=120.0,
                     help="time limit of the HiGHS re-solve timed beside the device crossover of config 2 (0: skip)")
     args = ap.parse_args()
@@ -459,6 +462,49 @@ def main():
         mn, am, bad = ctx.read_price(price)
         cnts = counts.download()
 
+    # ---- optional: iterations of the column-sharded projector CG on this rank's column block
+    sharded_cg = None
+    if args.cg_iters > 0:
+        from smart_crossover import distributed as D
+        if torch is None:
+            import torch
+            tstream = torch.cuda.Stream()
+            torch.cuda.set_stream(tstream)
+            ops = D.HipOps(Context(dev_index, tstream.cuda_stream), torch)
+        else:
+            ops = D.HipOps(ctx, torch)
+        A_loc = ops.matrix(sh.col_block.tocsr())                  # both layouts of the m x n_block column block
+        rng = np.random.default_rng(7)
+        xa = ops.vec(rng.uniform(0.1, 1.0, n_loc))
+        xs = ops.vec(np.where(rng.random(m) < 0.5, rng.uniform(0.1, 1.0, m), 0.0))
+        st = ops.cg_open(A_loc, xa, xs, ops.vec(sh.c), 1e-30)
+        if world > 1 and not rehearse:
+            dist.all_reduce(st["q"])
+        ops.cg_start(st)
+        for k in range(3):                                         # warm-up
+            ops.cg_local(st)
+            if world > 1 and not rehearse:
+                dist.all_reduce(st["q"])
+            ops.cg_update(st, k)
+        fence()
+        t_cg = time.perf_counter()
+        for k in range(args.cg_iters):
+            ops.cg_local(st)
+            if world > 1 and not rehearse:
+                dist.all_reduce(st["q"])
+            ops.cg_update(st, k + 3)
+        fence()
+        cg_elapsed = time.perf_counter() - t_cg
+        if world > 1:
+            tt = torch.tensor([cg_elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cg_elapsed = float(tt.item())
+        ops.cg_finish(st)
+        cg_bytes = 2 * 12 * nnz_loc + 8 * (3 * m + 2 * n_loc)      # K4 per iteration, this rank's block
+        sharded_cg = {"iterations": args.cg_iters, "ms_per_iteration": cg_elapsed / args.cg_iters * 1e3,
+                      "allreduce_bytes_per_iteration": 8 * m if world > 1 else 0,
+                      "algorithmic_GBps_per_gpu": cg_bytes / (cg_elapsed / args.cg_iters) / 1e9}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import lp_path as L     # checker / baseline only; never on the product path
@@ -509,6 +555,7 @@ def main():
             "kernels": kernels,
             "roofline_uniform": uniform,
             "cpu_baseline": cpu,
+            "sharded_cg": sharded_cg,
             "crossover": crossover,
             "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),
                        "min_rc": mn, "argmin": am, "n_violating": bad},

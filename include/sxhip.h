@@ -307,6 +307,40 @@ int sx_mask_f64_dev(sx_ctx *ctx, int64_t n, const double *src, const uint8_t *ma
 int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                       const double *c, double tol, int maxiter, sx_cg_result *result);
 
+/* ------------------------------------------------------------------ sharded variants (one process per GPU)
+ * K4 with the columns of Y sharded over ranks: the rank holds a column block A_loc (both
+ * layouts) with its slices xa_loc, c_loc; xs, cs and every m-vector are replicated.  Protocol, all calls
+ * asynchronous on the context's stream unless stated:
+ *   sx_cg_shard_open    this rank's share of b = Y v lands in *reduce_vec (device, m doubles)
+ *   [host: all-reduce(SUM) of reduce_vec over the ranks, on the same stream]
+ *   sx_cg_shard_start   takes the reduced b (blocking: returns ||b|| and whether the loop is trivial)
+ *   per iteration k = 0, 1, ...:  sx_cg_shard_local  (w = xa^2 .* A_loc^T p, q = A_loc w -> reduce_vec)
+ *                                 [host: all-reduce(SUM) of reduce_vec]
+ *                                 sx_cg_shard_update(k)  (slack block, alpha, z, r, stop test, beta, p)
+ *   sx_cg_shard_poll    (blocking) done flag and iteration count -- every few dozen iterations
+ *   sx_cg_shard_finish  (blocking) squared norm of this rank's columns of the projection (sum them over the
+ *                       ranks) and of the slack rows (identical on every rank: count once); optional vectors
+ * Kernels become no-ops once the stop test fired, so iterations enqueued past the end are harmless. */
+typedef struct sx_cg_shard sx_cg_shard;
+int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *xa_loc, const double *xs,
+                     const double *c_loc, const double *cs, double tol, sx_cg_shard **out, double **reduce_vec);
+int sx_cg_shard_start(sx_cg_shard *h, double *bnorm_out, int *trivial_out);
+int sx_cg_shard_local(sx_cg_shard *h);
+int sx_cg_shard_update(sx_cg_shard *h, int parity);
+int sx_cg_shard_poll(sx_cg_shard *h, int *done, int64_t *iters);
+int sx_cg_shard_finish(sx_cg_shard *h, double *proj_cols_loc, double *proj_rows, double *cols_sumsq,
+                       double *rows_sumsq, sx_cg_result *result);
+int sx_cg_shard_close(sx_cg_shard *h);
+/* K7 step by step for arcs sharded over ranks (network_methods/net_manager.py:165-182; BASELINE config 4): x_hat
+ * and the big-flow mask of the own arcs; node throughputs f_inv (and f) of the own node block A_rows (its rows
+ * over ALL arcs, row layout) from the all-gathered x_hat / mask; indicators of the own arc block A_cols (column
+ * layout) from the all-gathered f_inv.  Every sum is taken inside one rank, in the single-process order. */
+int sx_mcf_xhat_dev(sx_ctx *ctx, int64_t E, const double *x, const double *u, double *xhat, uint8_t *mask);
+int sx_mcf_node_flows_dev(sx_ctx *ctx, const sx_matrix *A_rows, const double *xhat_all, const uint8_t *mask_all,
+                          double *f_inv, double *f_out);
+int sx_mcf_arc_indicator_dev(sx_ctx *ctx, const sx_matrix *A_cols, const double *xhat_loc, const uint8_t *mask_loc,
+                             const double *f_inv_all, double *ind);
+
 /* ------------------------------------------------------------------ K16: device simplex
  * replaces the third-party re-solves behind the SolverCaller seam for the simplex family
  * (solver_caller/solving.py:32-68; call sites lp_methods/algorithms.py:69-74 and

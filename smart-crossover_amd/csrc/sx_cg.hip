@@ -548,3 +548,261 @@ SX_API int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, 
     SX_TRY(st.in(c, sizeof(double) * A->n, &dc));
     return sx_projector_norm_dev(ctx, A, (double *)dxa, (double *)dxs, (double *)dc, tol, maxiter, result);
 }
+
+// ------------------------------------------------------------------------------------------------------
+// The same CG with the columns of Y sharded over ranks (reference arithmetic
+// lp_methods/algorithms.py:183-187).  A rank holds a column block A_loc (m x n_loc, both layouts) with its
+// slice of xa and c; every m-vector (z, r, p, q, xs) is replicated and every rank performs the same vector
+// updates, so the only exchange per iteration is ONE all-reduce(SUM) of the partial product q = A_loc w_loc --
+// issued by the host between sx_cg_shard_local and sx_cg_shard_update on the stream the context runs on
+// (torch.distributed: RCCL over xGMI); the dot products are then taken from replicated vectors and need no
+// collective at all.  The slack block xs^2 .* p is added once, after the reduction.
+namespace {
+
+// q[i] += xs[i]^2 * p[i];  partial[block] = sum p[i]*q[i]
+__global__ __launch_bounds__(SX_WG) void k_cg_add_slack(const CgState *st, int64_t m, const double *__restrict__ xs,
+                                                        const double *__restrict__ p, double *__restrict__ q,
+                                                        double *__restrict__ partial) {
+    if (st->done) return;
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double s = xs[i], pi = p[i];
+        const double qi = q[i] + (s * s) * pi;
+        q[i] = qi;
+        acc += pi * qi;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// r = q (the reduced right-hand side), partial = sum r^2
+__global__ __launch_bounds__(SX_WG) void k_cg_take_rhs(int64_t m, const double *__restrict__ q, double *__restrict__ r,
+                                                       double *__restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const double v = q[i];
+        r[i] = v;
+        acc += v * v;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+} // namespace
+
+struct sx_cg_shard {
+    sx_ctx *ctx = nullptr;
+    const sx_matrix *A = nullptr;
+    const double *xa = nullptr, *xs = nullptr, *c = nullptr, *cs = nullptr;
+    double tol = 0.0, bnrm = 0.0;
+    int64_t m = 0, n = 0;
+    char *block = nullptr; // one allocation: state | partials | z r p q | w atz
+    CgState *st = nullptr;
+    double *ppq = nullptr, *prr = nullptr, *z = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *w = nullptr, *atz = nullptr;
+    int gT = 1, gA = 1, gv = 1, swzT = 0, swzA = 0, win_run = 0, nA = 1;
+    const sx_rowblock *rb = nullptr;
+};
+
+namespace {
+
+void shard_at(sx_cg_shard *h, const double *in, const double *scale, double *out) {
+    const sx_matrix *A = h->A;
+    hipStream_t s = h->ctx->stream;
+    if (h->win_run >= 4)
+        hipLaunchKernelGGL((k_cg_at_lw<4>), dim3(h->gT), dim3(SX_WG), 0, s, h->st, A->csc_tiles, A->n_csc_tiles, h->swzT,
+                           A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, h->m, in, scale, out);
+    else if (h->win_run >= 1)
+        hipLaunchKernelGGL((k_cg_at_lw<1>), dim3(h->gT), dim3(SX_WG), 0, s, h->st, A->csc_tiles, A->n_csc_tiles, h->swzT,
+                           A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, h->m, in, scale, out);
+    else
+        hipLaunchKernelGGL(k_cg_at, dim3(h->gT), dim3(SX_WG), 0, s, h->st, A->csc_tiles, A->n_csc_tiles, h->swzT, A->csc_ptr,
+                           A->csc_idx, A->csc_val, in, scale, out);
+}
+
+int shard_a(sx_cg_shard *h, const double *vec, double *out) { // out = A_loc vec, partials of out.out in ppq
+    const sx_matrix *A = h->A;
+    if (h->rb) return sx_rb_cg_a(h->ctx, h->rb, h->n, h->st, vec, h->xs, nullptr, out, h->ppq, CG_GRID, &h->nA);
+    hipLaunchKernelGGL(k_cg_a, dim3(h->gA), dim3(SX_WG), 0, h->ctx->stream, h->st, A->csr_tiles, A->n_csr_tiles, h->swzA,
+                       A->csr_ptr, A->csr_idx, A->csr_val, vec, h->xs, static_cast<const double *>(nullptr), out, h->ppq);
+    h->nA = h->gA;
+    return SX_OK;
+}
+
+} // namespace
+
+SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *xa_loc, const double *xs,
+                            const double *c_loc, const double *cs, double tol, sx_cg_shard **out, double **reduce_vec) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A_loc && out && reduce_vec, "NULL argument");
+    SX_REQUIRE(A_loc->csr_ptr && A_loc->csc_ptr, "the projector needs both layouts of the column block");
+    SX_REQUIRE(xa_loc && xs && c_loc, "xa, xs or c is NULL");
+    SX_REQUIRE(A_loc->m > 0 && tol >= 0, "empty row space or negative tolerance");
+    sx_cg_shard *h = new (std::nothrow) sx_cg_shard();
+    if (!h) {
+        sx_set_error("out of host memory");
+        return SX_ERR_NOMEM;
+    }
+    h->ctx = ctx;
+    h->A = A_loc;
+    h->xa = xa_loc;
+    h->xs = xs;
+    h->c = c_loc;
+    h->cs = cs;
+    h->tol = tol;
+    const int64_t m = h->m = A_loc->m, n = h->n = A_loc->n;
+    h->swzT = (ctx->opt_xcd_swizzle && A_loc->n_csc_tiles >= 64) ? 1 : 0;
+    h->swzA = (ctx->opt_xcd_swizzle && A_loc->n_csr_tiles >= 64) ? 1 : 0;
+    h->gT = grid_for(ctx, A_loc->n_csc_tiles);
+    h->gA = grid_for(ctx, A_loc->n_csr_tiles);
+    int64_t gv64 = ((m > n ? m : n) + 4 * SX_WG - 1) / (4 * SX_WG);
+    h->gv = static_cast<int>(gv64 < 1 ? 1 : (gv64 > 1024 ? 1024 : gv64));
+    int rc = sx_window_run_csc(ctx, A_loc, &h->win_run);
+    if (rc == SX_OK) rc = sx_rowblock_get(ctx, A_loc, &h->rb);
+    const size_t off_ppq = 256, off_prr = off_ppq + sizeof(double) * CG_GRID, off_vec = off_prr + sizeof(double) * CG_GRID;
+    const size_t bytes = off_vec + sizeof(double) * (4 * static_cast<size_t>(m) + 2 * static_cast<size_t>(n > 0 ? n : 1)) + 256;
+    if (rc == SX_OK && hipMalloc(reinterpret_cast<void **>(&h->block), bytes) != hipSuccess) {
+        sx_set_error("hipMalloc of %zu bytes failed for the sharded projector", bytes);
+        rc = SX_ERR_NOMEM;
+    }
+    if (rc != SX_OK) {
+        delete h;
+        return rc;
+    }
+    h->st = reinterpret_cast<CgState *>(h->block);
+    h->ppq = reinterpret_cast<double *>(h->block + off_ppq);
+    h->prr = reinterpret_cast<double *>(h->block + off_prr);
+    h->z = reinterpret_cast<double *>(h->block + off_vec);
+    h->r = h->z + m;
+    h->p = h->r + m;
+    h->q = h->p + m;
+    h->w = h->q + m;
+    h->atz = h->w + (n > 0 ? n : 1);
+    hipStream_t s = ctx->stream;
+    SX_HIP(hipMemsetAsync(h->st, 0, sizeof(CgState), s));
+    // this rank's share of b = Y v: A_loc (xa^2 .* c) -> q, to be summed over the ranks by the caller
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cg_scale_c, dim3(h->gv), dim3(SX_WG), 0, s, n, xa_loc, c_loc, h->w);
+        SX_TRY(shard_a(h, h->w, h->q));
+    } else {
+        SX_HIP(hipMemsetAsync(h->q, 0, sizeof(double) * static_cast<size_t>(m), s));
+    }
+    SX_HIP(hipGetLastError());
+    *out = h;
+    *reduce_vec = h->q;
+    return SX_OK;
+}
+
+SX_API int sx_cg_shard_start(sx_cg_shard *h, double *bnorm_out, int *trivial_out) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_device_guard guard(h->ctx->device);
+    hipStream_t s = h->ctx->stream;
+    const int64_t m = h->m;
+    hipLaunchKernelGGL(k_cg_take_rhs, dim3(h->gv), dim3(SX_WG), 0, s, m, h->q, h->r, h->ppq);
+    if (h->cs) hipLaunchKernelGGL(k_cg_slack_cost, dim3(h->gv), dim3(SX_WG), 0, s, m, h->xs, h->cs, h->r, h->ppq);
+    hipLaunchKernelGGL(k_cg_init, dim3(h->gv), dim3(SX_WG), 0, s, h->st, m, h->ppq, h->gv, h->r, h->p, h->z);
+    CgState host;
+    SX_HIP(hipMemcpyAsync(&host, h->st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    h->bnrm = sqrt(host.rho[0]);
+    const bool trivial = !(h->bnrm > h->tol) || (h->bnrm < h->tol * h->bnrm);
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, h->st, h->tol * h->bnrm, trivial ? 1 : 0);
+    SX_HIP(hipGetLastError());
+    if (bnorm_out) *bnorm_out = h->bnrm;
+    if (trivial_out) *trivial_out = trivial ? 1 : 0;
+    return SX_OK;
+}
+
+// w = xa^2 .* (A_loc^T p);  q = A_loc w   -- then the caller all-reduces q (the vector sx_cg_shard_open returned)
+SX_API int sx_cg_shard_local(sx_cg_shard *h) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_device_guard guard(h->ctx->device);
+    if (h->n > 0) {
+        shard_at(h, h->p, h->xa, h->w);
+        SX_TRY(shard_a(h, h->w, h->q));
+    }
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+// with q reduced over the ranks: q += xs^2 .* p, alpha, z, r, beta, p  (iteration number = parity of rho's slot)
+SX_API int sx_cg_shard_update(sx_cg_shard *h, int parity) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_device_guard guard(h->ctx->device);
+    hipStream_t s = h->ctx->stream;
+    const int64_t m = h->m;
+    hipLaunchKernelGGL(k_cg_add_slack, dim3(h->gv), dim3(SX_WG), 0, s, h->st, m, h->xs, h->p, h->q, h->ppq);
+    hipLaunchKernelGGL(k_cg_update_zr, dim3(h->gv), dim3(SX_WG), 0, s, h->st, parity & 1, m, h->ppq, h->gv, h->p, h->q, h->z,
+                       h->r, h->prr);
+    hipLaunchKernelGGL(k_cg_update_p, dim3(h->gv), dim3(SX_WG), 0, s, h->st, parity & 1, m, h->prr, h->gv, h->r, h->p);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_cg_shard_poll(sx_cg_shard *h, int *done, int64_t *iters) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_device_guard guard(h->ctx->device);
+    CgState host;
+    SX_HIP(hipMemcpyAsync(&host, h->st, sizeof(host), hipMemcpyDeviceToHost, h->ctx->stream));
+    SX_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (done) *done = host.done;
+    if (iters) *iters = host.iters;
+    return SX_OK;
+}
+
+// squared norms of this rank's part of the projection: its columns xa .* (c - A_loc^T z) (optionally written to
+// proj_cols_loc) and the slack rows (identical on every rank: count them once); converged / iterations of the loop
+SX_API int sx_cg_shard_finish(sx_cg_shard *h, double *proj_cols_loc, double *proj_rows, double *cols_sumsq,
+                              double *rows_sumsq, sx_cg_result *result) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_device_guard guard(h->ctx->device);
+    hipStream_t s = h->ctx->stream;
+    const int64_t m = h->m, n = h->n;
+    CgState host;
+    SX_HIP(hipMemcpyAsync(&host, h->st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    const long long iters = host.iters;
+    const int converged = host.converged;
+    const double rel = h->bnrm > 0 ? sqrt(host.rho[host.iters & 1]) / h->bnrm : 0.0;
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, h->st, h->tol * h->bnrm, 0); // re-arm the kernels
+    double cols = 0.0, rows = 0.0;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cg_ones, dim3(h->gv), dim3(SX_WG), 0, s, n, h->w);
+        shard_at(h, h->z, h->w, h->atz);
+        hipLaunchKernelGGL(k_cg_proj_cols, dim3(h->gv), dim3(SX_WG), 0, s, n, h->xa, h->c, h->atz, h->ppq, proj_cols_loc);
+    } else {
+        SX_HIP(hipMemsetAsync(h->ppq, 0, sizeof(double) * h->gv, s));
+    }
+    hipLaunchKernelGGL(k_cg_proj_rows, dim3(h->gv), dim3(SX_WG), 0, s, m, h->xs, h->cs, h->z, h->prr, proj_rows);
+    // the two sums separately: k_cg_finish adds them, so run it once per term against a zeroed partner
+    SX_HIP(hipMemsetAsync(h->w, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, h->st, h->ppq, h->gv, h->w, 1);
+    SX_HIP(hipMemcpyAsync(&host, h->st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    cols = host.sumsq;
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, h->st, h->prr, h->gv, h->w, 1);
+    SX_HIP(hipMemcpyAsync(&host, h->st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    rows = host.sumsq;
+    SX_HIP(hipGetLastError());
+    if (cols_sumsq) *cols_sumsq = cols;
+    if (rows_sumsq) *rows_sumsq = rows;
+    if (result) {
+        memset(result, 0, sizeof(*result));
+        result->b_norm = h->bnrm;
+        result->iters = iters;
+        result->converged = converged;
+        result->rel_residual = rel;
+    }
+    return SX_OK;
+}
+
+SX_API int sx_cg_shard_close(sx_cg_shard *h) {
+    if (!h) return SX_OK;
+    sx_device_guard guard(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->block) (void)hipFree(h->block);
+    delete h;
+    return SX_OK;
+}

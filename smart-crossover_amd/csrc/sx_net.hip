@@ -226,6 +226,48 @@ SX_API int sx_flow_indicator_mcf_dev(sx_ctx *ctx, const sx_matrix *A, const doub
     return SX_OK;
 }
 
+// The three steps of K7 one by one, for arcs sharded over ranks (BASELINE config 4): a rank owns a
+// block of arcs (x, u, its incidence columns) and a block of nodes (their rows over ALL arcs).  x_hat of the own
+// arcs -> all-gather -> node throughputs of the own nodes from the full x_hat (each node sums its arcs in
+// ascending order: the sums of the single-process kernel, bit for bit) -> all-gather of f_inv -> indicators of
+// the own arcs.  No floating-point value is ever added across ranks.
+SX_API int sx_mcf_xhat_dev(sx_ctx *ctx, int64_t E, const double *x, const double *u, double *xhat, uint8_t *mask) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(E >= 0, "E < 0");
+    if (E == 0) return SX_OK;
+    SX_REQUIRE(x && u && xhat && mask, "NULL argument");
+    hipLaunchKernelGGL(k_mcf_xhat, dim3(grid1d(E)), dim3(SX_WG), 0, ctx->stream, E, x, u, xhat, mask);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_mcf_node_flows_dev(sx_ctx *ctx, const sx_matrix *A_rows, const double *xhat_all, const uint8_t *mask_all,
+                                 double *f_inv, double *f_out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A_rows && xhat_all && mask_all && f_inv, "NULL argument");
+    SX_REQUIRE(A_rows->csr_ptr != nullptr, "the node block needs the row layout");
+    if (A_rows->m == 0) return SX_OK;
+    const int swz = ctx->opt_xcd_swizzle;
+    const unsigned grid = swz ? static_cast<unsigned>(((A_rows->n_csr_tiles + 7) >> 3) << 3)
+                              : static_cast<unsigned>(A_rows->n_csr_tiles);
+    hipLaunchKernelGGL(k_mcf_throughput, dim3(grid), dim3(SX_WG), 0, ctx->stream, A_rows->csr_tiles, A_rows->n_csr_tiles,
+                       swz, A_rows->csr_ptr, A_rows->csr_idx, A_rows->csr_val, xhat_all, mask_all, f_inv, f_out);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+SX_API int sx_mcf_arc_indicator_dev(sx_ctx *ctx, const sx_matrix *A_cols, const double *xhat_loc, const uint8_t *mask_loc,
+                                    const double *f_inv_all, double *ind) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A_cols && xhat_loc && mask_loc && f_inv_all && ind, "NULL argument");
+    SX_REQUIRE(A_cols->csc_ptr != nullptr, "the arc block needs the column layout");
+    if (A_cols->n == 0) return SX_OK;
+    hipLaunchKernelGGL(k_mcf_indicator, dim3(grid1d(A_cols->n)), dim3(SX_WG), 0, ctx->stream, A_cols->n, A_cols->csc_ptr,
+                       A_cols->csc_idx, A_cols->csc_val, xhat_loc, mask_loc, f_inv_all, ind);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
 SX_API int sx_flow_indicator_ot_dev(sx_ctx *ctx, int64_t S, int64_t D, const double *X, const double *s,
                                     const double *d, double *ind) {
     SX_ENTER(ctx);

@@ -129,3 +129,324 @@ class Exchange:
         t = torch.tensor([value], dtype=torch.float64, device=self.device or "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+
+# ======================================================================================================
+# Sharded problems: the crossover host path with an LP / MCF spread over the ranks of one node
+# ======================================================================================================
+# What a rank computes locally is behind a small "ops" object -- ``HipOps`` below drives libsxhip.so on the
+# rank's GPU with torch tensors as device vectors (so that RCCL can operate on them); the CPU rehearsal of the
+# test-suite plugs in an object with the same methods -- and everything that crosses ranks is a
+# ``torch.distributed`` collective issued here.  No floating-point value is ever summed across ranks except
+# the one m-vector per CG iteration: scores, index sets, right-hand sides and flow indicators
+# of the sharded path are bit-identical to the single-GPU path.
+
+
+class HipOps:
+    """Rank-local kernels: libsxhip.so on this rank's GPU.  Vectors are torch CUDA tensors; a kernel sees them
+    through ``Context.wrap`` (no copies).  ``stream`` = the torch stream the context was created on, so kernels
+    and collectives are ordered without host synchronisation."""
+
+    def __init__(self, ctx, torch_module):
+        self.ctx, self.torch = ctx, torch_module
+        self.device = f"cuda:{ctx.device}"
+
+    # ---- vectors
+    def vec(self, host: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(host)).to(self.device)
+
+    def empty(self, n: int, dtype):
+        return self.torch.empty(int(n), dtype={np.float64: self.torch.float64, np.uint8: self.torch.uint8,
+                                               np.int64: self.torch.int64}[dtype], device=self.device)
+
+    def host(self, t) -> np.ndarray:
+        return t.cpu().numpy()
+
+    def _w(self, t):
+        if t is None:
+            return None
+        dt = {self.torch.float64: np.float64, self.torch.uint8: np.uint8, self.torch.int64: np.int64,
+              self.torch.int8: np.int8}[t.dtype]
+        return self.ctx.wrap(t.data_ptr(), t.numel(), dt, owner=t)
+
+    # ---- matrices
+    def matrix(self, csr):
+        return self.ctx.matrix(csr)
+
+    def row_matrix(self, csr):
+        return self.ctx.row_shard(csr)
+
+    # ---- LP kernels
+    def score_columns(self, A, y, c, x, l, u, gamma, code):
+        self.ctx.score_columns(A, self._w(y), self._w(c), self._w(x), self._w(l), self._w(u), gamma, None, self._w(code))
+
+    def score_rows(self, A_rows, x, b, y, gamma_dual, flag):
+        self.ctx.score_rows(A_rows, self._w(x), self._w(b), self._w(y), gamma_dual, None, self._w(flag))
+
+    def count(self, flags, mask: int) -> int:
+        return int(self.ctx.where(self._w(flags), mask).size)
+
+    def price(self, A, y, c, vbasis, tol) -> Tuple[float, int, int]:
+        return self.ctx.read_price(self.ctx.price(A, self._w(y), self._w(c), self._w(vbasis), tol, None))
+
+    def fixed_rhs(self, A_rows, code_all, u_all, l_all, b_loc, out):
+        self.ctx.fixed_rhs(A_rows, self._w(code_all), self._w(u_all), self._w(l_all), self._w(b_loc), self._w(out))
+
+    # ---- sharded CG (sx_cg_shard_*)
+    def cg_open(self, A, xa, xs, c, tol):
+        import ctypes as C
+        h, vec = C.c_void_p(), C.c_void_p()
+        keep = (self._w(xa), self._w(xs), self._w(c))
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_cg_shard_open(self.ctx.handle, A.handle, keep[0].ptr, keep[1].ptr, keep[2].ptr, None,
+                                                float(tol), C.byref(h), C.byref(vec)))
+        m = A.shape[0]
+        # the reduce vector as a torch tensor over the library's buffer: RCCL reduces it in place
+        q = self._as_tensor(vec.value, m)
+        return {"h": h, "q": q, "keep": keep}
+
+    def _as_tensor(self, ptr: int, n: int):
+        class _Cai:            # __cuda_array_interface__ view of foreign device memory
+            def __init__(self, p, k):
+                self.__cuda_array_interface__ = {"shape": (k,), "typestr": "<f8", "data": (p, False), "version": 2}
+        return self.torch.as_tensor(_Cai(ptr, n), device=self.device)
+
+    def cg_start(self, s) -> Tuple[float, bool]:
+        import ctypes as C
+        from smart_crossover.hip import lib as _l
+        bn, tr = C.c_double(0), C.c_int(0)
+        _l.check(self.ctx._lib.sx_cg_shard_start(s["h"], C.byref(bn), C.byref(tr)))
+        return float(bn.value), bool(tr.value)
+
+    def cg_local(self, s):
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_cg_shard_local(s["h"]))
+
+    def cg_update(self, s, k: int):
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_cg_shard_update(s["h"], int(k) & 1))
+
+    def cg_poll(self, s) -> Tuple[bool, int]:
+        import ctypes as C
+        from smart_crossover.hip import lib as _l
+        d, it = C.c_int(0), C.c_int64(0)
+        _l.check(self.ctx._lib.sx_cg_shard_poll(s["h"], C.byref(d), C.byref(it)))
+        return bool(d.value), int(it.value)
+
+    def cg_finish(self, s) -> Tuple[float, float, int, bool]:
+        import ctypes as C
+        from smart_crossover.hip import lib as _l
+        cols, rows, res = C.c_double(0), C.c_double(0), _l.CgResult()
+        _l.check(self.ctx._lib.sx_cg_shard_finish(s["h"], None, None, C.byref(cols), C.byref(rows), C.byref(res)))
+        _l.check(self.ctx._lib.sx_cg_shard_close(s["h"]))
+        return float(cols.value), float(rows.value), int(res.iters), bool(res.converged)
+
+    # ---- MCF kernels
+    def mcf_xhat(self, x, u, xhat, mask):
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_mcf_xhat_dev(self.ctx.handle, x.numel(), x.data_ptr(), u.data_ptr(), xhat.data_ptr(),
+                                               mask.data_ptr()))
+
+    def mcf_node_flows(self, A_rows, xhat_all, mask_all, f_inv):
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_mcf_node_flows_dev(self.ctx.handle, A_rows.handle, xhat_all.data_ptr(), mask_all.data_ptr(),
+                                                     f_inv.data_ptr(), None))
+
+    def mcf_arc_indicator(self, A_cols, xhat, mask, f_inv_all, ind):
+        from smart_crossover.hip import lib as _l
+        _l.check(self.ctx._lib.sx_mcf_arc_indicator_dev(self.ctx.handle, A_cols.handle, xhat.data_ptr(), mask.data_ptr(),
+                                                        f_inv_all.data_ptr(), ind.data_ptr()))
+
+    def top_k(self, key, k: int):
+        """(keys, local indices) of the k largest keys, descending key, ties by descending index (the library's rule)."""
+        order = self.ctx.argsort_desc(self._w(key))
+        order.size, order.nbytes = int(k), int(k) * 8                      # the first k ranks only
+        keys = self.ctx.gather(order, self._w(key)).download()
+        return keys, order.download()
+
+
+def _ops_default(dist):
+    """HipOps on this rank's GPU (LOCAL_RANK), with the library context created ON torch's current stream so that
+    kernels, tensor copies and RCCL collectives are ordered without host synchronisation.  torch's default stream
+    has handle 0, which the library reads as "create your own": an explicit stream is made current first."""
+    import os
+    import torch
+    from smart_crossover.hip import Context
+    dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    return HipOps(Context(dev, stream.cuda_stream), torch)
+
+
+class ShardedLP:
+    """One rank's share of a GeneralLP ``min c^T x, A x (=|<) b, l <= x <= u``: a column block of A (both layouts;
+    K1 scoring, K10 pricing, the CG's two products, compaction) and a row block (row layout; K2 scoring, the
+    exact right-hand side of the sub-problem).  ``x`` and ``y`` -- the inputs of the crossover -- are replicated.
+
+    Reference arithmetic: lp_methods/algorithms.py:79-111 (get_perturb_problem), :162-193 (projector),
+    lp_methods/lp_manager.py:57-64 (right-hand side)."""
+
+    def __init__(self, lp, dist=None, ops=None, blocks: Optional[Tuple[List[Block], List[Block]]] = None):
+        import scipy.sparse as sp
+        self.ex = Exchange(dist, None)
+        self.dist = dist
+        self.ops = ops if ops is not None else _ops_default(dist)
+        if hasattr(self.ops, "device"):
+            self.ex.device = self.ops.device
+        A = sp.csr_matrix(lp.A)
+        self.m, self.n = A.shape
+        world, rank = self.ex.world, self.ex.rank
+        if blocks is None:
+            blocks = (split_by_nnz(sp.csc_matrix(A).indptr, world), split_by_nnz(A.indptr, world))
+        self.col_blocks, self.row_blocks = blocks
+        self.cols, self.rows = self.col_blocks[rank], self.row_blocks[rank]
+        cs, ce, rs, re = self.cols.start, self.cols.stop, self.rows.start, self.rows.stop
+        self.A_cols = self.ops.matrix(A[:, cs:ce].tocsr())            # m x n_loc, both layouts
+        self.A_rows = self.ops.row_matrix(A[rs:re, :].tocsr())         # m_loc x n, row layout
+        v = self.ops.vec
+        self.c_loc, self.l_loc, self.u_loc = v(lp.c[cs:ce]), v(lp.l[cs:ce]), v(lp.u[cs:ce])
+        self.b_loc = v(lp.b[rs:re])
+        self.l_all, self.u_all = v(lp.l), v(lp.u)
+        self.lt = np.asarray(lp.sense) == "<"
+        self.n_lt = int(np.count_nonzero(self.lt))
+
+    # ---- K1 + K2 + set sizes + K10 ------------------------------------------------------------------
+    def scoring_pass(self, x: np.ndarray, y: np.ndarray, gamma: float, gamma_dual: float):
+        """Column codes of the own columns, row flags of the own rows, global sizes of the three index sets."""
+        o = self.ops
+        cs, ce, rs, re = self.cols.start, self.cols.stop, self.rows.start, self.rows.stop
+        x_all, y_all = o.vec(x), o.vec(y)
+        self.code_loc = o.empty(self.cols.size, np.uint8)
+        self.flag_loc = o.empty(self.rows.size, np.uint8)
+        o.score_columns(self.A_cols, y_all, self.c_loc, x_all[cs:ce], self.l_loc, self.u_loc, gamma, self.code_loc)
+        o.score_rows(self.A_rows, x_all, self.b_loc, y_all[rs:re], gamma_dual, self.flag_loc)
+        import torch
+        counts = torch.tensor([o.count(self.code_loc, 1), o.count(self.code_loc, 2), o.count(self.flag_loc, 0xFF)],
+                              dtype=torch.int64, device=getattr(o, "device", "cpu"))
+        counts = self.ex.sum_counts(counts)
+        return self.code_loc, self.flag_loc, [int(t) for t in counts.cpu()]
+
+    def price(self, y: np.ndarray, vbasis_loc: Optional[np.ndarray] = None, tol: float = 1e-6):
+        """Global pricing result (min reduced cost, its global column, violations): one 24-byte all-gather."""
+        o = self.ops
+        vb = o.vec(vbasis_loc.astype(np.int8)) if vbasis_loc is not None else None
+        rec = o.price(self.A_cols, o.vec(y), self.c_loc, vb, tol)
+        return self.ex.gather_price(rec, [b.start for b in self.col_blocks])
+
+    # ---- K4: projector norm, columns of Y sharded -----------------------------------------------------
+    def projector_norm(self, xa: np.ndarray, xs: np.ndarray, tol: float = 1e-8, maxiter: int = 1000, poll: int = 25):
+        """|| (I - Y^T (Y Y^T)^+ Y) [xa .* c ; 0] || with Y = [A diag(xa), diag(xs)]: one all-reduce of an m-vector
+        per CG iteration.  ``xa`` (n) and ``xs`` (m) are replicated host vectors."""
+        o = self.ops
+        cs, ce = self.cols.start, self.cols.stop
+        s = o.cg_open(self.A_cols, o.vec(xa[cs:ce]), o.vec(xs), self.c_loc, tol)
+        self._allreduce(s["q"])
+        bnorm, trivial = o.cg_start(s)
+        it = 0
+        done = trivial
+        while not done and it < maxiter:
+            upto = min(it + poll, maxiter)
+            for k in range(it, upto):
+                o.cg_local(s)
+                self._allreduce(s["q"])
+                o.cg_update(s, k)
+            it = upto
+            done, _ = o.cg_poll(s)
+        cols, rows, iters, converged = o.cg_finish(s)
+        import torch
+        t = torch.tensor([cols], dtype=torch.float64, device=getattr(o, "device", "cpu"))
+        self._allreduce(t)
+        return float(np.sqrt(float(t.item()) + rows)), iters, converged
+
+    def _allreduce(self, t):
+        if self.dist is not None:
+            self.dist.all_reduce(t)
+
+    def _allgather(self, t, sizes: Sequence[int]):
+        """Concatenation of every rank's 1-D tensor (blocks may differ in length)."""
+        import torch
+        if self.dist is None:
+            return t
+        # collectives want equal shapes: pad the local block to the longest one, gather, cut the padding out
+        longest = int(max(sizes))
+        mine = torch.zeros(longest, dtype=t.dtype, device=t.device)
+        mine[:t.numel()] = t
+        out = torch.empty(longest * len(sizes), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, mine)
+        return torch.cat([out[r * longest:r * longest + int(k)] for r, k in enumerate(sizes)])
+
+    # ---- K6: right-hand side of the sub-problem, exact --------------------------------------------------
+    def sub_problem_rhs(self):
+        """b - A[:, fix_up] u - A[:, fix_low] l for the own rows after ``scoring_pass`` -- every row is summed by
+        the rank that owns it, over all columns, so the result equals the single-GPU one bit for bit; the codes
+        of the other ranks' columns arrive by one all-gather of a byte per column."""
+        o = self.ops
+        code_all = self._allgather(self.code_loc, [b.size for b in self.col_blocks])
+        out = o.empty(self.rows.size, np.float64)
+        o.fixed_rhs(self.A_rows, code_all, self.u_all, self.l_all, self.b_loc, out)
+        return out
+
+
+class ShardedMCF:
+    """Arcs of a min-cost-flow problem sharded over ranks (BASELINE config 4): flow indicators and their ranking
+    (network_methods/net_manager.py:156-184).  A rank owns a block of arcs (their x, u and incidence columns) and a
+    block of nodes (their rows over all arcs)."""
+
+    def __init__(self, mcf, dist=None, ops=None):
+        import scipy.sparse as sp
+        self.ex = Exchange(dist, None)
+        self.dist = dist
+        self.ops = ops if ops is not None else _ops_default(dist)
+        if hasattr(self.ops, "device"):
+            self.ex.device = self.ops.device
+        A = sp.csr_matrix(mcf.A)
+        self.V, self.E = A.shape
+        world, rank = self.ex.world, self.ex.rank
+        self.arc_blocks, self.node_blocks = split_even(self.E, world), split_by_nnz(A.indptr, world)
+        self.arcs, self.nodes = self.arc_blocks[rank], self.node_blocks[rank]
+        self.A_cols = self.ops.matrix(A[:, self.arcs.start:self.arcs.stop].tocsr())
+        self.A_rows = self.ops.row_matrix(A[self.nodes.start:self.nodes.stop, :].tocsr())
+        self.u_loc = self.ops.vec(np.asarray(mcf.u, dtype=np.float64)[self.arcs.start:self.arcs.stop])
+
+    _allgather = ShardedLP._allgather
+
+    def flow_indicators(self, x_loc: np.ndarray):
+        """Indicators of the own arcs from the own slice of the inexact flow."""
+        o = self.ops
+        x = o.vec(np.asarray(x_loc, dtype=np.float64))
+        xhat, mask = o.empty(self.arcs.size, np.float64), o.empty(self.arcs.size, np.uint8)
+        o.mcf_xhat(x, self.u_loc, xhat, mask)
+        sizes = [b.size for b in self.arc_blocks]
+        xhat_all, mask_all = self._allgather(xhat, sizes), self._allgather(mask, sizes)
+        f_inv = o.empty(self.nodes.size, np.float64)
+        o.mcf_node_flows(self.A_rows, xhat_all, mask_all, f_inv)
+        f_inv_all = self._allgather(f_inv, [b.size for b in self.node_blocks])
+        self.ind_loc = o.empty(self.arcs.size, np.float64)
+        o.mcf_arc_indicator(self.A_cols, xhat, mask, f_inv_all, self.ind_loc)
+        return self.ind_loc
+
+    def top_arcs(self, k: int) -> np.ndarray:
+        """Global indices of the k arcs with the largest indicators, ranked as the single-GPU queue ranks them
+        (descending indicator, ties by descending arc index): each rank ranks its own arcs, the W candidate lists
+        of length <= k are all-gathered and merged -- only queue *prefixes* are ever consumed
+        (network_methods/algorithms.py:114-115), so no global sort is needed."""
+        import torch
+        o = self.ops
+        kk = min(int(k), self.arcs.size)
+        keys, idx = o.top_k(self.ind_loc, kk)
+        rec = np.zeros((int(k), 2), dtype=np.float64)
+        rec[:, 0] = -np.inf
+        rec[:kk, 0] = keys
+        rec[:kk, 1] = (idx + self.arcs.start).astype(np.float64)       # arc indices are exact in a double (< 2^53)
+        t = torch.from_numpy(rec.reshape(-1))
+        if self.dist is not None:
+            t = t.to(getattr(o, "device", "cpu"))
+            parts = [torch.empty_like(t) for _ in range(self.ex.world)]
+            self.dist.all_gather(parts, t)
+            allrec = np.concatenate([p.cpu().numpy().reshape(-1, 2) for p in parts])
+        else:
+            allrec = rec
+        allrec = allrec[allrec[:, 0] > -np.inf]
+        order = np.lexsort((-allrec[:, 1], -allrec[:, 0]))               # key descending, then index descending
+        return allrec[order[:int(k)], 1].astype(np.int64)

@@ -108,6 +108,16 @@ PROTOTYPES = {
     "sx_x_real_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "sx_mask_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
+    "sx_cg_shard_open": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, C.POINTER(_vp), C.POINTER(_vp)]),
+    "sx_cg_shard_start": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_int)]),
+    "sx_cg_shard_local": (_int, [_vp]),
+    "sx_cg_shard_update": (_int, [_vp, _int]),
+    "sx_cg_shard_poll": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64)]),
+    "sx_cg_shard_finish": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(CgResult)]),
+    "sx_cg_shard_close": (_int, [_vp]),
+    "sx_mcf_xhat_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sx_mcf_node_flows_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sx_mcf_arc_indicator_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_simplex_solve_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                     C.POINTER(SimplexResult)]),
     "sx_simplex_crossover_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,

@@ -47,3 +47,16 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, structure):
     assert res["codes_equal"] and res["flags_equal"]
     assert res["counts"] == res["counts_want"] and sum(res["counts"]) > 0
     assert res["price"] == res["price_want"]
+
+
+def test_sharded_lp_and_mcf_with_the_real_kernels(tmp_path):
+    """The product's ShardedLP / ShardedMCF (smart_crossover/distributed.py) with HipOps: two ranks, both on device
+    0, collectives over gloo -- K1/K2/K10, the sharded projector CG (sx_cg_shard_*: one m-vector all-reduce per
+    iteration), the exact sharded right-hand side, arcs-over-ranks flow indicators (sx_mcf_*_dev) and the merged
+    top-k -- against the single-process oracle."""
+    sys.path.insert(0, HERE)
+    from test_dist_gloo import check_sharded_results, run_workers
+    res = run_workers("_dist_worker2.py", tmp_path / "res.json", 2,
+                      {"SX_DIST_OPS": "hip", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LOCAL_RANK": "0"})
+    assert res["world"] == 2
+    check_sharded_results(res)
