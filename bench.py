@@ -270,6 +270,14 @@ def main():
         tstream = torch.cuda.Stream()
         torch.cuda.set_stream(tstream)
         stream = tstream.cuda_stream
+    elif args.cg_iters > 0:
+        # the sharded-CG step hands torch tensors to the kernels: torch has to bring its HIP runtime up BEFORE the
+        # library does (the other order leaves torch without a device), and both must share one stream
+        import torch
+        torch.cuda.set_device(dev_index)
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
     ctx = Context(dev_index, stream)
     dev_name, cus, hbm = ctx.device_info()
 
@@ -466,13 +474,7 @@ def main():
     sharded_cg = None
     if args.cg_iters > 0:
         from smart_crossover import distributed as D
-        if torch is None:
-            import torch
-            tstream = torch.cuda.Stream()
-            torch.cuda.set_stream(tstream)
-            ops = D.HipOps(Context(dev_index, tstream.cuda_stream), torch)
-        else:
-            ops = D.HipOps(ctx, torch)
+        ops = D.HipOps(ctx, torch)
         A_loc = ops.matrix(sh.col_block.tocsr())                  # both layouts of the m x n_block column block
         rng = np.random.default_rng(7)
         xa = ops.vec(rng.uniform(0.1, 1.0, n_loc))

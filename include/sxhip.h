@@ -307,6 +307,17 @@ int sx_mask_f64_dev(sx_ctx *ctx, int64_t n, const double *src, const uint8_t *ma
 int sx_projector_norm(sx_ctx *ctx, const sx_matrix *A, const double *xa, const double *xs,
                       const double *c, double tol, int maxiter, sx_cg_result *result);
 
+/* Free-variable branch of get_projector_Xc (lp_methods/algorithms.py:173-180: cg on the normal equations of the
+ * free columns, adjusted cost, then a Gurobi QP) on the device: free_idx[nf] (device, ascending) names the free
+ * columns, xa[n] / xs[m] the scales of the structural / slack columns, row_lt[m] the '<' rows.  The QP is solved
+ * in penalty form by the same CG (free columns at a large scale, zero cost).  proj_cols[n] / proj_rows[m] receive
+ * the projection on the QP's variables -- entries of free columns and of '=' rows are zero -- and
+ * result->proj_norm its norm.  Parity with Gurobi is unpinned; tests compare with the exact QP minimiser.
+ * Blocking. */
+int sx_projector_free_dev(sx_ctx *ctx, const sx_matrix *A, int64_t nf, const int64_t *free_idx, const double *xa,
+                          const double *xs, const double *c, const uint8_t *row_lt, double *proj_cols,
+                          double *proj_rows, sx_cg_result *result);
+
 /* ------------------------------------------------------------------ sharded variants (one process per GPU)
  * K4 with the columns of Y sharded over ranks: the rank holds a column block A_loc (both
  * layouts) with its slices xa_loc, c_loc; xs, cs and every m-vector are replicated.  Protocol, all calls

@@ -806,3 +806,215 @@ SX_API int sx_cg_shard_close(sx_cg_shard *h) {
     delete h;
     return SX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Free-variable branch of get_projector_Xc (reference lp_methods/algorithms.py:173-180):
+//     t = cg(A_2^T A_2, c_free, tol 1e-8, 1000 iterations);   c' = c_std[non-free] - A_1^T (A_2 t)
+//     projection of X_1 c' onto {x : A_1 X_1 x + A_2 f = 0}        (a Gurobi QP in the reference)
+// with A_2 the free columns and A_1 the other columns of the standard-form matrix [A, I_<].  Everything runs on
+// the device: the normal equations of the free block by the same CG kernels with the two products swapped,
+// the adjusted cost by one column pass (K1), and the QP as the limit of the ordinary projector in which the free
+// columns carry a large scale tau and zero cost -- the penalty form, error O((||Y|| / (tau sigma_min(A_2)))^2);
+// tau = 100 x the largest ordinary column scale, corrected for the ratio of column norms.  Parity with Gurobi's
+// loose-tolerance answer is unpinned (no Gurobi); tests compare with the exact minimiser of the QP.
+namespace {
+
+__global__ __launch_bounds__(SX_WG) void k_free_flags(int64_t nf, const int64_t *__restrict__ free_idx,
+                                                      uint8_t *__restrict__ is_free) {
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; k < nf;
+         k += static_cast<int64_t>(gridDim.x) * SX_WG)
+        is_free[free_idx[k]] = 1;
+}
+
+// per column: squared norm; maxima as bit patterns of non-negative doubles: [0] all columns, [1] -(min over free
+// columns) is awkward, so [1] holds the max of 1 / sqnorm over the free columns; [2] max xa over the non-free
+__global__ __launch_bounds__(SX_WG) void k_free_column_stats(int64_t n, const int64_t *__restrict__ colptr,
+                                                             const double *__restrict__ val,
+                                                             const uint8_t *__restrict__ is_free,
+                                                             const double *__restrict__ xa,
+                                                             unsigned long long *__restrict__ stats) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        double s = 0.0;
+        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) s += val[e] * val[e];
+        a = fmax(a, s);
+        if (is_free[j]) b = fmax(b, s > 0.0 ? 1.0 / s : INFINITY);
+        else c = fmax(c, xa[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmax(a, __shfl_down(a, o, 64));
+        b = fmax(b, __shfl_down(b, o, 64));
+        c = fmax(c, __shfl_down(c, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[0], static_cast<unsigned long long>(__double_as_longlong(a)));
+        atomicMax(&stats[1], static_cast<unsigned long long>(__double_as_longlong(b)));
+        atomicMax(&stats[2], static_cast<unsigned long long>(__double_as_longlong(c)));
+    }
+}
+
+__global__ __launch_bounds__(SX_WG) void k_free_max(int64_t m, const double *__restrict__ v, unsigned long long *slot) {
+    double a = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG)
+        a = fmax(a, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_down(a, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, static_cast<unsigned long long>(__double_as_longlong(a)));
+}
+
+// xa2 = xa with tau on the free columns; c_adj zeroed there
+__global__ __launch_bounds__(SX_WG) void k_free_apply(int64_t n, const uint8_t *__restrict__ is_free, double tau,
+                                                      const double *__restrict__ xa, double *__restrict__ xa2,
+                                                      double *__restrict__ c_adj) {
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        const bool f = is_free[j] != 0;
+        xa2[j] = f ? tau : xa[j];
+        if (f) c_adj[j] = 0.0;
+    }
+}
+
+// cs[i] = row '<' ? -g[i] : 0
+__global__ __launch_bounds__(SX_WG) void k_free_slack_cost(int64_t m, const uint8_t *__restrict__ row_lt,
+                                                           const double *__restrict__ g, double *__restrict__ cs) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; i < m;
+         i += static_cast<int64_t>(gridDim.x) * SX_WG)
+        cs[i] = row_lt[i] ? -g[i] : 0.0;
+}
+
+// partial sums of pc[j]^2 over non-free columns (mode 0) or pr[i]^2 over '<' rows (mode 1); masked-out entries are
+// also zeroed in place so that the vectors handed back cover the QP's variables only
+__global__ __launch_bounds__(SX_WG) void k_free_norm(int64_t n, const uint8_t *__restrict__ flag, int keep_when,
+                                                     double *__restrict__ v, double *__restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; j < n;
+         j += static_cast<int64_t>(gridDim.x) * SX_WG) {
+        if ((flag[j] != 0) == (keep_when != 0)) acc += v[j] * v[j];
+        else v[j] = 0.0;
+    }
+    const double tot = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+inline double from_bits(unsigned long long b) {
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+} // namespace
+
+SX_API int sx_projector_free_dev(sx_ctx *ctx, const sx_matrix *A, int64_t nf, const int64_t *free_idx, const double *xa,
+                                 const double *xs, const double *c, const uint8_t *row_lt, double *proj_cols,
+                                 double *proj_rows, sx_cg_result *result) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A && free_idx && xa && xs && c && row_lt && proj_cols && proj_rows && result, "NULL argument");
+    SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the projector needs both layouts of A");
+    SX_REQUIRE(nf > 0 && nf <= A->n, "nf must be in 1 .. n");
+    const int64_t m = A->m, n = A->n;
+    hipStream_t s = ctx->stream;
+    sx_stage tmp(ctx); // device temporaries, freed on return
+    void *v_isfree, *v_stats, *v_cfree, *v_t, *v_r, *v_p, *v_g, *v_w, *v_cadj, *v_xa2, *v_cs, *v_ones, *v_st, *v_pa, *v_pb;
+    SX_TRY(tmp.in(nullptr, static_cast<size_t>(n), &v_isfree));
+    SX_TRY(tmp.in(nullptr, 4 * sizeof(unsigned long long), &v_stats));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_cfree));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_t));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_r));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_p));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_g));   // A_2^T w  (nf)
+    SX_TRY(tmp.in(nullptr, sizeof(double) * m, &v_w));    // A_2 p, later g = A_2 t  (m)
+    SX_TRY(tmp.in(nullptr, sizeof(double) * n, &v_cadj));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * n, &v_xa2));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * m, &v_cs));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * nf, &v_ones));
+    SX_TRY(tmp.in(nullptr, 256, &v_st));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * CG_GRID, &v_pa));
+    SX_TRY(tmp.in(nullptr, sizeof(double) * CG_GRID, &v_pb));
+    uint8_t *is_free = static_cast<uint8_t *>(v_isfree);
+    unsigned long long *stats = static_cast<unsigned long long *>(v_stats);
+    double *c_free = static_cast<double *>(v_cfree), *t = static_cast<double *>(v_t), *r = static_cast<double *>(v_r);
+    double *p = static_cast<double *>(v_p), *g = static_cast<double *>(v_g), *w = static_cast<double *>(v_w);
+    double *c_adj = static_cast<double *>(v_cadj), *xa2 = static_cast<double *>(v_xa2), *cs = static_cast<double *>(v_cs);
+    double *ones = static_cast<double *>(v_ones), *pa = static_cast<double *>(v_pa), *pb = static_cast<double *>(v_pb);
+    CgState *st = static_cast<CgState *>(v_st);
+    auto g1 = [](int64_t k) {
+        int64_t b = (k + 4 * SX_WG - 1) / (4 * SX_WG);
+        return dim3(static_cast<unsigned>(b < 1 ? 1 : (b > 1024 ? 1024 : b)));
+    };
+    SX_HIP(hipMemsetAsync(is_free, 0, static_cast<size_t>(n), s));
+    SX_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), s));
+    SX_HIP(hipMemsetAsync(st, 0, sizeof(CgState), s));
+    hipLaunchKernelGGL(k_free_flags, g1(nf), dim3(SX_WG), 0, s, nf, free_idx, is_free);
+
+    // ---- t = cg(A_2^T A_2, c_free): the CG kernels with the row pass first (w = A_2 p, alpha = rho / (w.w))
+    sx_matrix *A2 = nullptr;
+    SX_TRY(sx_gather_columns_dev(ctx, A, free_idx, nf, &A2));
+    struct Guard {
+        sx_matrix *M;
+        ~Guard() { (void)sx_matrix_destroy(M); }
+    } guard{A2};
+    SX_TRY(sx_gather_f64_dev(ctx, nf, free_idx, c, c_free));
+    const int swzT = (ctx->opt_xcd_swizzle && A2->n_csc_tiles >= 64) ? 1 : 0;
+    const int swzA = (ctx->opt_xcd_swizzle && A2->n_csr_tiles >= 64) ? 1 : 0;
+    const int gT = grid_for(ctx, A2->n_csc_tiles), gA = grid_for(ctx, A2->n_csr_tiles);
+    const dim3 gv = g1(nf);
+    hipLaunchKernelGGL(k_cg_ones, gv, dim3(SX_WG), 0, s, nf, ones);
+    hipLaunchKernelGGL(k_cg_take_rhs, gv, dim3(SX_WG), 0, s, nf, c_free, r, pa);             // r = c_free, partials r.r
+    hipLaunchKernelGGL(k_cg_init, gv, dim3(SX_WG), 0, s, st, nf, pa, static_cast<int>(gv.x), r, p, t);
+    CgState host;
+    SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    const double bn = sqrt(host.rho[0]);
+    const bool trivial = !(bn > 1e-8);
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, st, 1e-8 * bn, trivial ? 1 : 0);
+    if (!trivial) {
+        for (int it = 0; it < 1000; ++it) {
+            hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A2->csr_tiles, A2->n_csr_tiles, swzA, A2->csr_ptr,
+                               A2->csr_idx, A2->csr_val, p, static_cast<const double *>(nullptr),
+                               static_cast<const double *>(nullptr), w, pa);                 // w = A_2 p, partials w.w
+            hipLaunchKernelGGL(k_cg_at, dim3(gT), dim3(SX_WG), 0, s, st, A2->csc_tiles, A2->n_csc_tiles, swzT, A2->csc_ptr,
+                               A2->csc_idx, A2->csc_val, w, ones, g);                        // g = A_2^T w
+            hipLaunchKernelGGL(k_cg_update_zr, gv, dim3(SX_WG), 0, s, st, it & 1, nf, pa, gA, p, g, t, r, pb);
+            hipLaunchKernelGGL(k_cg_update_p, gv, dim3(SX_WG), 0, s, st, it & 1, nf, pb, static_cast<int>(gv.x), r, p);
+            if ((it % 25) == 24) {
+                SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+                SX_HIP(hipStreamSynchronize(s));
+                if (host.done) break;
+            }
+        }
+    }
+    // ---- g = A_2 t (m-vector), adjusted cost c - A^T g on the structurals (zero on the free ones), -g on the slacks
+    hipLaunchKernelGGL(k_cg_set_atol, dim3(1), dim3(1), 0, s, st, 0.0, 0);                   // re-arm
+    hipLaunchKernelGGL(k_cg_a, dim3(gA), dim3(SX_WG), 0, s, st, A2->csr_tiles, A2->n_csr_tiles, swzA, A2->csr_ptr,
+                       A2->csr_idx, A2->csr_val, t, static_cast<const double *>(nullptr), static_cast<const double *>(nullptr),
+                       w, pa);
+    SX_TRY(sx_score_columns_dev(ctx, A, w, c, nullptr, nullptr, nullptr, 0.0, c_adj, nullptr));
+    hipLaunchKernelGGL(k_free_slack_cost, g1(m), dim3(SX_WG), 0, s, m, row_lt, w, cs);
+    // ---- scale of the free columns
+    hipLaunchKernelGGL(k_free_column_stats, g1(n), dim3(SX_WG), 0, s, n, A->csc_ptr, A->csc_val, is_free, xa, stats);
+    hipLaunchKernelGGL(k_free_max, g1(m), dim3(SX_WG), 0, s, m, xs, stats + 3);
+    unsigned long long hs[4];
+    SX_HIP(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    const double norm_max = sqrt(from_bits(hs[0]));
+    const double inv_min_free = from_bits(hs[1]); // max of 1 / ||a_j||^2 over the free columns
+    const double norm_min_free = (inv_min_free > 0 && inv_min_free < INFINITY) ? sqrt(1.0 / inv_min_free) : 0.0;
+    const double scale_max = fmax(from_bits(hs[2]), from_bits(hs[3]));
+    const double ratio = norm_min_free > 0 ? norm_max / norm_min_free : 1.0;
+    const double tau = 100.0 * fmax(scale_max, 1e-300) * fmax(1.0, ratio);
+    hipLaunchKernelGGL(k_free_apply, g1(n), dim3(SX_WG), 0, s, n, is_free, tau, xa, xa2, c_adj);
+    // ---- the penalised projector, then the norm over the QP's own variables (non-free columns, '<' rows)
+    SX_TRY(sx_projector_std_dev(ctx, A, xa2, xs, c_adj, cs, 1e-8, 1000, proj_cols, proj_rows, result));
+    const dim3 gn = g1(n), gm = g1(m);
+    hipLaunchKernelGGL(k_free_norm, gn, dim3(SX_WG), 0, s, n, is_free, 0, proj_cols, pa);
+    hipLaunchKernelGGL(k_free_norm, gm, dim3(SX_WG), 0, s, m, row_lt, 1, proj_rows, pb);
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(SX_WG), 0, s, st, pa, static_cast<int>(gn.x), pb, static_cast<int>(gm.x));
+    SX_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    SX_HIP(hipGetLastError());
+    result->proj_norm = sqrt(host.sumsq);
+    return SX_OK;
+}

@@ -268,7 +268,10 @@ class HipOps:
 def _ops_default(dist):
     """HipOps on this rank's GPU (LOCAL_RANK), with the library context created ON torch's current stream so that
     kernels, tensor copies and RCCL collectives are ordered without host synchronisation.  torch's default stream
-    has handle 0, which the library reads as "create your own": an explicit stream is made current first."""
+    has handle 0, which the library reads as "create your own": an explicit stream is made current first.  torch
+    must have initialised its HIP runtime before the first library context of the process exists (the other order
+    leaves torch without a device): create the ShardedLP / ShardedMCF before any other smart_crossover device call,
+    or pass ``ops=HipOps(ctx, torch)`` with a context made on a torch stream."""
     import os
     import torch
     from smart_crossover.hip import Context

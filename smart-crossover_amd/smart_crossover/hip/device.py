@@ -227,6 +227,13 @@ class Context:
                                                 C.byref(res)))
         return res
 
+    def projector_free(self, A, free_idx, xa, xs, c, row_lt, proj_cols, proj_rows) -> "_l.CgResult":
+        """Free-variable branch of the projector (sx_projector_free_dev, blocking)."""
+        res = _l.CgResult()
+        _l.check(self._lib.sx_projector_free_dev(self.handle, A.handle, free_idx.size, free_idx.ptr, _ptr(xa), _ptr(xs),
+                                                 _ptr(c), _ptr(row_lt), _ptr(proj_cols), _ptr(proj_rows), C.byref(res)))
+        return res
+
     def simplex(self, A, b, c, l, u, row_is_lt, vbasis=None, cbasis=None, max_iter=0, feas_tol=1e-7, opt_tol=1e-7,
                 x=None, y=None, vbasis_out=None, cbasis_out=None, session: Optional["SimplexSession"] = None,
                 col_ids: Optional[np.ndarray] = None, x_start=None) -> "_l.SimplexResult":

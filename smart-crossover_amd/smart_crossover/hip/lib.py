@@ -108,6 +108,7 @@ PROTOTYPES = {
     "sx_x_real_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "sx_mask_f64_dev": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "sx_projector_norm_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _int, C.POINTER(CgResult)]),
+    "sx_projector_free_dev": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(CgResult)]),
     "sx_cg_shard_open": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, C.POINTER(_vp), C.POINTER(_vp)]),
     "sx_cg_shard_start": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_int)]),
     "sx_cg_shard_local": (_int, [_vp]),

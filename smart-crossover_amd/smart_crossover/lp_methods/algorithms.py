@@ -119,52 +119,25 @@ def _projector_device(dv: _Resident, xa, xs, c, tol: float, max_iter: int, want_
     return info, pc, pr
 
 
-FREE_COLUMN_WEIGHT = 100.0     # penalty scale of the free columns relative to the largest ordinary scale
-
-
-def _free_column_scale(A_cols_norm_max: float, A_free_norm_min: float, scale_max: float) -> float:
-    """Scale tau given to free columns in the penalty form of the reference's QP.  The minimiser of
-    ||x - v||^2 + ||f||^2 / tau^2 over {Y x + A_2 f = 0} tends to the QP's with an error of order
-    (||Y|| / (tau sigma_min(A_2)))^2; with tau = 100 x the largest ordinary column scale (corrected for
-    the ratio of column norms) that is ~1e-7 relative while CG still converges (1e4 x does not)."""
-    ratio = A_cols_norm_max / A_free_norm_min if A_free_norm_min > 0 else 1.0
-    return FREE_COLUMN_WEIGHT * max(scale_max, 1e-300) * max(1.0, ratio)
-
-
 def _projector_free_device(lp: GeneralLP, dv: _Resident, x_real, xs, want_vector: bool):
-    """Free-variable branch of get_projector_Xc (lp_methods/algorithms.py:173-180) on the device.
+    """Free-variable branch of get_projector_Xc (lp_methods/algorithms.py:173-180) on the device
+    (``sx_projector_free_dev``, csrc/sx_cg.hip).
 
     Reference: t = cg(A_2^T A_2, c_free); c' = c_std[nonfree] - A_1^T A_2 t; then the Gurobi QP
-    min ||x - X_1 c'||^2 s.t. A_1 X_1 x + A_2 f = 0.  Here the QP is the limit of the ordinary projector
-    in which the free columns carry a large scale tau and zero cost, so the same matrix-free CG (K4)
-    serves; only the adjusted cost is new: its structural part is c - A^T g with g = A_2 t (one column
-    scoring pass, K1), its slack part -g on the '<' rows.  Parity with the reference is unpinned (no
-    Gurobi); tests compare with the exact minimiser of the QP (oracle.projector_Xc_free)."""
-    from scipy.sparse.linalg import cg as _cg
+    min ||x - X_1 c'||^2 s.t. A_1 X_1 x + A_2 f = 0.  The library solves the normal equations of the free block
+    with its CG kernels, forms the adjusted cost with one column pass (K1) and takes the QP as the limit of the
+    ordinary projector in which the free columns carry a large scale tau and zero cost (penalty form).  Parity
+    with the reference is unpinned (no Gurobi); tests compare with the exact minimiser of the QP
+    (oracle.projector_Xc_free)."""
     ctx, m, n = dv.ctx, dv.m, dv.n
     free = lp.get_free_ind()
-    A = sp.csc_matrix(lp.A)
-    A2 = A[:, free]
-    trans, _ = _cg(A2.T @ A2, np.asarray(lp.c, dtype=np.float64)[free], rtol=1e-8, atol=0.0, maxiter=1000)
-    g = A2 @ trans
-    g_dev = ctx.to_device(np.ascontiguousarray(g, dtype=np.float64))
-    c_adj_dev = ctx.empty(n, np.float64)
-    ctx.score_columns(dv.res.A, g_dev, dv.c, None, None, None, 0.0, c_adj_dev, None)      # c - A^T g
-    c_adj = c_adj_dev.download()
-    c_adj[free] = 0.0
-    xa = x_real.download()
-    xs_host = xs.download()
-    col_norm = np.sqrt(np.asarray(A.multiply(A).sum(axis=0)).ravel())
-    tau = _free_column_scale(float(col_norm.max(initial=0.0)), float(col_norm[free].min()),
-                             max(float(np.delete(xa, free).max(initial=0.0)), float(xs_host.max(initial=0.0))))
-    xa[free] = tau
-    cs = np.where(np.asarray(lp.sense) == "<", -g, 0.0)
     pc, pr = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
-    info = ctx.projector_norm(dv.res.A, ctx.to_device(xa), xs, ctx.to_device(c_adj), 1e-8, 1000, pc, pr,
-                              cs=ctx.to_device(cs))
-    # the free block of the penalised projection is f / tau, not part of the QP's x: leave it out
-    proj = np.concatenate([np.delete(pc.download(), free), pr.download()[np.asarray(lp.sense) == "<"]])
-    info.proj_norm = float(np.linalg.norm(proj))
+    info = ctx.projector_free(dv.res.A, ctx.to_device(np.ascontiguousarray(free, dtype=np.int64)), x_real, xs, dv.c,
+                              dv.res.lt, pc, pr)
+    proj = None
+    if want_vector:
+        # the free block of the penalised projection is f / tau, not part of the QP's x: it is left out
+        proj = np.concatenate([np.delete(pc.download(), free), pr.download()[np.asarray(lp.sense) == "<"]])
     return info, proj, None
 
 
@@ -217,9 +190,16 @@ def get_perturb_problem(lp: GeneralLP, x: np.ndarray, y: np.ndarray, gamma: floa
 
     fix_low, fix_up = ctx.where(code, 1), ctx.where(code, 2)
     fixed = ctx.where(code, 3)
-    keep = np.ones(n, dtype=bool)
-    keep[fixed] = False
-    manager._adopt_partition(code, fix_low, fix_up, np.flatnonzero(keep).astype(np.int64), fixed)
+    compacted = None
+    if fixed.size:
+        # K6 now: the compaction hands back the kept columns' indices (device stream compaction), so the
+        # complement of the fixed set is not recomputed on the host
+        sub_matrix, non_fix_dev = ctx.compact_columns(dv.res.A, code)
+        compacted = (sub_matrix, non_fix_dev)
+        non_fix = non_fix_dev.download()
+    else:
+        non_fix = np.arange(n, dtype=np.int64)
+    manager._adopt_partition(code, fix_low, fix_up, non_fix, fixed, compacted)
     manager.fix_constraints(ctx.where(flag))
     print("  The number of fixed variables is %d." % manager.get_num_fixed_variables())
     print("  The number of fixed constraints is %d." % manager.get_num_fixed_constraints())
@@ -300,14 +280,13 @@ def apply_projector_qp(A: sp.csr_matrix, v: np.ndarray, A_f: Optional[sp.csr_mat
     A, A_f = sp.csr_matrix(A), sp.csr_matrix(A_f)
     m, n = A.shape
     nf = A_f.shape[1]
+    # the same device routine with unit scales: columns [A, A_f], the last nf of them free, cost v on the first n
     both = sp.hstack([A, A_f], format="csr")
-    col_norm = np.sqrt(np.asarray(both.multiply(both).sum(axis=0)).ravel())
-    tau = _free_column_scale(float(col_norm[:n].max(initial=0.0)), float(col_norm[n:].min(initial=np.inf)), 1.0)
     dY = ctx.matrix(both)
-    pc = ctx.empty(n + nf, np.float64)
-    ctx.projector_norm(dY, ctx.to_device(np.concatenate([np.ones(n), np.full(nf, tau)])), ctx.to_device(np.zeros(m)),
-                       ctx.to_device(np.concatenate([np.asarray(v, dtype=np.float64), np.zeros(nf)])), 1e-8, 1000,
-                       pc, None)
+    pc, pr = ctx.empty(n + nf, np.float64), ctx.empty(m, np.float64)
+    ctx.projector_free(dY, ctx.to_device(np.arange(n, n + nf, dtype=np.int64)), ctx.to_device(np.ones(n + nf)),
+                       ctx.to_device(np.zeros(m)), ctx.to_device(np.concatenate([np.asarray(v, dtype=np.float64), np.zeros(nf)])),
+                       ctx.to_device(np.zeros(m, dtype=np.uint8)), pc, pr)
     out = pc.download()[:n]
     dY.free()
     return out

@@ -45,6 +45,7 @@ class LPManager:
         self.var_info = {"non_fix": np.arange(self.n, dtype=_I64), "fix_low": empty, "fix_up": empty, "fix": empty}
         self.fixed_constraints = empty
         self._dev_code = None          # per-column code already on the device (set by get_perturb_problem)
+        self._compacted = None         # (sub-matrix, kept columns) when get_perturb_problem has compacted already
 
     # ------------------------------------------------------------------ partition
     def _code_host(self) -> np.ndarray:
@@ -64,11 +65,14 @@ class LPManager:
         self.var_info["non_fix"] = np.flatnonzero(keep).astype(_I64)
         self.var_info["fix"] = np.flatnonzero(~keep).astype(_I64)
         self._dev_code = None
+        self._compacted = None
 
-    def _adopt_partition(self, dev_code, fix_low, fix_up, non_fix, fix) -> None:
-        """Partition computed on the device by get_perturb_problem (same sets as fix_variables)."""
+    def _adopt_partition(self, dev_code, fix_low, fix_up, non_fix, fix, compacted=None) -> None:
+        """Partition computed on the device by get_perturb_problem (same sets as fix_variables); ``compacted`` =
+        (sub-matrix, kept column indices) when the compaction has already run."""
         self.var_info.update(fix_low=fix_low, fix_up=fix_up, non_fix=non_fix, fix=fix)
         self._dev_code = dev_code
+        self._compacted = compacted
 
     def fix_constraints(self, ind_fix_to_up: np.ndarray) -> None:
         self.fixed_constraints = _idx(ind_fix_to_up)
@@ -90,7 +94,8 @@ class LPManager:
             ctx = res.ctx
             code = self._dev_code if self._dev_code is not None else ctx.to_device(self._code_host())
             d_b, d_c, d_l, d_u = (res.put(v) for v in (self.lp.b, self.lp.c, self.lp.l, self.lp.u))
-            sub_matrix, non_fix = ctx.compact_columns(res.A, code)
+            sub_matrix, non_fix = self._compacted if self._compacted is not None else ctx.compact_columns(res.A, code)
+            self._compacted = None
             if non_fix.size != self.var_info["non_fix"].size:
                 raise RuntimeError("device partition disagrees with var_info")      # cannot happen; cheap guard
             b_sub = ctx.empty(self.m, np.float64)

@@ -112,3 +112,20 @@ def test_projector_config2_size_hits_cap(ctx, capsys):
         print(f"\n[K4 @c2] device {gpu_s*1e3:.0f} ms (incl. upload) vs CPU matrix-free {cpu_s:.1f} s; "
               f"proj_norm {res.proj_norm:.6e} vs {np.linalg.norm(proj):.6e} (ratio {ratio:.4f}), rel_resid {res.rel_residual:.2e}")
     assert 0.5 < ratio < 2.0
+
+
+def test_projector_of_a_row_less_lp_is_the_identity():
+    """m = 0: Y is empty, the projector of the reference returns v unchanged (algorithms.py:183-187) -- norm ||xa .* c||,
+    not 0 -- and a row-less LP is not mistaken for a feasibility problem."""
+    import scipy.sparse as sp
+    from smart_crossover.hip import Context
+    ctx = Context(0)
+    n = 37
+    rng = np.random.default_rng(2)
+    xa, c = rng.uniform(0.1, 1, n), rng.standard_normal(n)
+    dA = ctx.matrix(sp.csr_matrix((0, n)))
+    pc = ctx.empty(n, np.float64)
+    res = ctx.projector_norm(dA, ctx.to_device(xa), ctx.to_device(np.zeros(0)), ctx.to_device(c), 1e-8, 100, pc, None)
+    assert res.proj_norm == pytest.approx(float(np.linalg.norm(xa * c)), rel=1e-14)
+    np.testing.assert_array_equal(pc.download(), xa * c)
+    ctx.close()
