@@ -146,11 +146,13 @@ __device__ __forceinline__ void price_combine(double &v, long long &ix, double v
     }
 }
 
+// `scratch`: 3 * SX_WG / 64 doubles of LDS that nobody else is using any more (the walk kernels hand over their
+// product buffer after a barrier, so that the reduction does not add to the static LDS that bounds their occupancy)
 __device__ __forceinline__ void price_block_reduce(double v, long long ix, long long bad,
-                                                   PricePartial *out_slot) {
-    __shared__ double sv[SX_WG / 64];
-    __shared__ long long si[SX_WG / 64];
-    __shared__ long long sb[SX_WG / 64];
+                                                   PricePartial *out_slot, double *scratch) {
+    double *sv = scratch;
+    long long *si = reinterpret_cast<long long *>(scratch + SX_WG / 64);
+    long long *sb = reinterpret_cast<long long *>(scratch + 2 * (SX_WG / 64));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         double v2 = __shfl_down(v, o, 64);
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(SX_WG) void k_price(
             if (rc == rc) price_combine(v, ix, rc, j); // NaN never becomes the minimum
         }
     }
-    price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
+    __syncthreads(); // the last tile's sums are out of the product buffer
+    price_block_reduce(v, ix, bad, &partial[blockIdx.x], lds.v[0]);
 }
 
 // K10 behind the LDS operand window: grid-stride over runs of RUN tiles, one window load per run
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(SX_WG) void k_price_lw(
             }
         }
     }
-    price_block_reduce(v, ix, bad, &partial[blockIdx.x]);
+    __syncthreads(); // the last tile's sums are out of the product buffer
+    price_block_reduce(v, ix, bad, &partial[blockIdx.x], lds.v[0]);
 }
 
 __global__ __launch_bounds__(SX_WG) void k_price_final(const PricePartial *__restrict__ partial,
@@ -285,7 +289,8 @@ __global__ __launch_bounds__(SX_WG) void k_price_final(const PricePartial *__res
         bad += partial[b].n_bad;
     }
     __shared__ PricePartial one;
-    price_block_reduce(v, ix, bad, &one);
+    __shared__ double scratch[3 * (SX_WG / 64)];
+    price_block_reduce(v, ix, bad, &one, scratch);
     __syncthreads();
     if (threadIdx.x == 0) {
         out->min_rc = (one.argmin >= 0) ? one.min_rc : NAN;

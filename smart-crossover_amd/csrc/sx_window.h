@@ -13,7 +13,8 @@
 #include "sx_segwalk.h"
 
 constexpr int SXL_CAP = 4096;   // window length in doubles (32 KiB of LDS)
-constexpr int SXL_CHUNK = 2048; // staged entries per chunk of the windowed walk (16 KiB of LDS)
+constexpr int SXL_CHUNK = 1024; // staged entries per chunk of the windowed walk: 8 KiB of LDS, so that window + chunk
+                                // = 40 KiB and FOUR workgroups share a CU (2048: three; K1 0.341 -> 0.312 ms at c5)
 
 struct sx_stage_win {
     const double *__restrict__ vec;

@@ -83,8 +83,9 @@ def main():
     print(f"workload {args.workload}/{structure} window={args.window}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
     print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med) | K10 med ms   min ms   GB/s(med)")
     for v in variants:
+        extra = f"/{v[4]}" if len(v) > 4 else ""
         a, b, p10 = np.array(res[v]["k1"]), np.array(res[v]["k2"]), np.array(res[v]["k10"])
-        print(f" {v[0]} {v[1]:2d}  {v[2]:4d} {v[3]:3d} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
+        print(f" {v[0]} {v[1]:2d}  {v[2]:4d} {v[3]:3d}{extra} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
               f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f} |"
               f"  {np.median(p10):8.4f} {p10.min():8.4f} {k10_bytes/np.median(p10)/1e6:9.0f}")
 
