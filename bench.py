@@ -172,14 +172,19 @@ def crossover_lp_c5():
                         "CG iteration on one core"}
 
 
+# the sources K1 / K2 / K10 are compiled from: their HBM traffic depends on nothing else
+WALK_SOURCES = ("sx_segwalk.h", "sx_window.h", "sx_window.hip", "sx_lp_kernels.hip", "sx_rowblock.h", "sx_rowblock.hip",
+                "sx_rowblock_build.hip", "sx_tiles.hip", "sx_sort.hip", "sx_internal.h")
+
+
 def source_hash() -> str:
-    """sha256 over the kernel sources: a PMC traffic figure is only reused for the build it was measured on."""
-    import glob
+    """sha256 over the sources of the walk kernels: a PMC traffic figure is only reused for the build it was
+    measured on."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "smart-crossover_amd", "csrc", "*"))):
-        h.update(os.path.basename(path).encode())
-        h.update(open(path, "rb").read())
+    for name in WALK_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "smart-crossover_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -412,10 +417,18 @@ def main():
     traffic = None
     try:
         import glob
+        # the kernels that can stand behind each of the three walks (the one with launches in the PMC pass ran)
+        behind = {"k_score_columns": ("k_score_columns_lw", "k_score_columns"), "k_score_rows": ("k_rb_score_rows", "k_score_rows"),
+                  "k_price": ("k_price_lw", "k_price")}
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "kernel_traffic.json")), reverse=True):
             rec = json.load(open(path))
             if rec.get("workload") == f"{args.workload}/{structure}" and rec.get("source_hash") == source_hash():
-                traffic = rec.get("traffic_bytes_per_launch", {}).get(dominant)
+                per = rec.get("traffic_bytes_per_launch", {})
+                for name, cands in behind.items():
+                    got = next((per[c] for c in cands if c in per), None)
+                    kernels[name]["traffic_bytes"] = got
+                    kernels[name]["traffic_source"] = os.path.relpath(path, ROOT)
+                traffic = kernels[dominant].get("traffic_bytes")
                 break
     except Exception:
         traffic = None
