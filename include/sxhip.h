@@ -368,7 +368,8 @@ int sx_mcf_arc_indicator_dev(sx_ctx *ctx, const sx_matrix *A_cols, const double 
  * (device, any may be NULL): x[n], y[m] with reduced cost = c - A^T y, vbasis[n], cbasis[m].  Blocking.  All
  * arrays device. */
 typedef struct sx_simplex_result {
-    int64_t status;          /* 0 optimal, 1 infeasible, 2 unbounded, 3 iteration limit, 4 numerical trouble */
+    int64_t status;          /* 0 optimal, 1 infeasible, 2 unbounded, 3 iteration limit, 4 numerical trouble,
+                              * 5 (sx_netsimplex_dev only) problem or start basis outside the solver's domain */
     int64_t iters;           /* pivots and bound flips, both phases */
     int64_t phase1_iters;
     int64_t warm_start_used; /* 1 when the given basis was installed, 2 when a session's inverse was reused */
@@ -392,6 +393,20 @@ int sx_simplex_crossover_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
                              const int8_t *cbasis_in, const double *x_start, int64_t max_iter, double feas_tol,
                              double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
                              sx_simplex_result *result);
+
+/* Network simplex (K16n) for the re-solves of the network crossover (network_methods/net_manager.py:211-222
+ * solve_subproblem -> solve_mcf / solve_ot with warm_start_basis; the reference hands these to Gurobi's /
+ * CPLEX's simplex).  A must be a node-arc incidence matrix -- every column exactly one +1 (tail row) and one
+ * -1 (head row) -- with l = 0 <= x <= u (u may be +inf), all rows equalities, and (vbasis_in, cbasis_in) a
+ * primal feasible spanning-tree basis: vbasis 0 on m - 1 arcs that connect all rows, -1 / -2 elsewhere, cbasis
+ * 0 on exactly one row (the root, whose dual is 0).  Then: primal network simplex on the tree (preorder
+ * arrays, block pricing, one persistent workgroup; csrc/sx_netsimplex.hip), outputs as sx_simplex_solve_dev.
+ * result->status 5 = outside that domain (not a network, not a tree, tree flows out of bounds): nothing was
+ * solved and the caller falls back on sx_simplex_solve_dev, which has a phase 1.  Blocking; arrays device. */
+int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                      const double *u, const int8_t *vbasis_in, const int8_t *cbasis_in, int64_t max_iter,
+                      double feas_tol, double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
+                      sx_simplex_result *result);
 
 /* ------------------------------------------------------------------ entropic OT warm start
  * The step before the OT crossover in the reference's driver (scripts/run_network_crossover.py:95-97:

@@ -94,6 +94,9 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_chunk = static_cast<int>(value);
     } else if (!strcmp(key, "window")) {
         ctx->opt_window = value < 0 ? -1 : static_cast<int>(value);
+    } else if (!strcmp(key, "ns_block")) {
+        SX_REQUIRE(value >= 0 && value <= 64, "ns_block must be 0 (by size) or 1..64 arcs per lane");
+        ctx->opt_ns_block = static_cast<int>(value);
     } else if (!strcmp(key, "graph")) {
         ctx->opt_graph = value ? 1 : 0;
     } else if (!strcmp(key, "spx_defer")) {

@@ -263,6 +263,16 @@ class Context:
             _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
 
+    def net_simplex(self, A, b, c, l, u, vbasis, cbasis, max_iter=0, feas_tol=1e-7, opt_tol=1e-7, x=None, y=None,
+                    vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
+        """K16n (blocking): primal network simplex from a spanning-tree basis; status 5 = the problem or the
+        basis is outside its domain (the caller then takes ``simplex``)."""
+        res = _l.SimplexResult()
+        _l.check(self._lib.sx_netsimplex_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(vbasis),
+                                             _ptr(cbasis), int(max_iter), float(feas_tol), float(opt_tol), _ptr(x),
+                                             _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+        return res
+
     def simplex_session(self) -> "SimplexSession":
         return SimplexSession(self)
 

@@ -59,6 +59,7 @@ class HipCaller(SolverCaller):
         self._warm = None
         self._warm_point = None
         self._res = None
+        self._network = False
 
     def read_genlp(self, genlp: GeneralLP) -> None:
         self._load(genlp.A, genlp.b, genlp.c, genlp.l, genlp.u, np.asarray(genlp.sense) == "<")
@@ -76,6 +77,11 @@ class HipCaller(SolverCaller):
         self._col_ids = getattr(stdlp, "col_ids", None)
         self._session_holder = getattr(stdlp, "hip_session", None)
         self._dev_matrix = getattr(stdlp, "_sx_device_matrix", None)
+
+    def read_mcf(self, mcf) -> None:
+        # a MinCostFlow is a network by construction (formats.py:104-121); sx_netsimplex_dev checks the columns
+        self.read_stdlp(mcf)
+        self._network = True
 
     def get_A(self) -> sp.csr_matrix:
         return self._A
@@ -171,10 +177,21 @@ class HipCaller(SolverCaller):
                 holder.session = ctx.simplex_session()
             session = holder.session
         t0 = time.perf_counter()
-        self._res = ctx.simplex(dA, put(self._b), put(self._c), put(self._l), put(self._u), ctx.to_device(self._row_lt),
-                                vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb,
-                                session=None if x_start is not None else session,
-                                col_ids=None if x_start is not None else col_ids, x_start=x_start)
+        d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
+        self._res = None
+        if self._network and vb_in is not None and x_start is None and not self._row_lt.any():
+            # a network sub-problem with a warm tree basis: network simplex on the tree (K16n); status 5 = the
+            # basis is not a primal feasible spanning tree (or A is no incidence matrix): general simplex below
+            res = ctx.net_simplex(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol),
+                                  d_x, d_y, d_vb, d_cb)
+            if int(res.status) != 5:
+                self._res = res
+        self.solved_by = "netsimplex" if self._res is not None else "simplex"
+        if self._res is None:
+            self._res = ctx.simplex(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt),
+                                    vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb,
+                                    session=None if x_start is not None else session,
+                                    col_ids=None if x_start is not None else col_ids, x_start=x_start)
         self._runtime = time.perf_counter() - t0
         self._x, self._y = d_x.download(), d_y.download()
         self._vb, self._cb = d_vb.download().astype(int), d_cb.download().astype(int)
