@@ -94,6 +94,11 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_chunk = static_cast<int>(value);
     } else if (!strcmp(key, "window")) {
         ctx->opt_window = value < 0 ? -1 : static_cast<int>(value);
+    } else if (!strcmp(key, "netsimplex")) {
+        SX_REQUIRE(value >= -1 && value <= 1, "netsimplex must be -1 (by size), 0 (off) or 1 (whenever it applies)");
+        ctx->opt_netsimplex = static_cast<int>(value);
+    } else if (!strcmp(key, "ns_lds")) {
+        ctx->opt_ns_lds = value ? 1 : 0;
     } else if (!strcmp(key, "ns_block")) {
         SX_REQUIRE(value >= 0 && value <= 64, "ns_block must be 0 (by size) or 1..64 arcs per lane");
         ctx->opt_ns_block = static_cast<int>(value);

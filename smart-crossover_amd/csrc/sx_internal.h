@@ -75,6 +75,8 @@ struct sx_ctx {
     int opt_rowblock = -1;   // column-blocked row layout of the row walk: -1 auto, 0 off, 1 whenever possible
     int opt_spx_check = 2048; // K16: pivots between two checks of A x + s = b (drift of the explicit inverse)
     int opt_spx_force_reinvert = 0; // K16, tests: rebuild the inverse at every check whatever the residual says
+    int opt_netsimplex = -1; // K16n for network re-solves: -1 by size, 0 never (general simplex), 1 whenever it applies
+    int opt_ns_lds = 1;      // K16n: tree arrays and potentials in LDS when they fit (V <= 4608)
     int opt_ns_block = 0;    // K16n network simplex: arcs priced per lane and block (0: by size, 1..64)
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
 };

@@ -9,9 +9,10 @@
 // each short, so the whole solve is ONE persistent workgroup of 1024 lanes that never returns to the host:
 //   price    all lanes: a block of arcs, reduced cost c - y[tail] + y[head], best violation by wave shuffles
 //            (block search: the cursor moves on, a full empty round proves optimality);
-//   cycle    two lanes, one per end of the entering arc, climb to the join node and record their paths;
-//            the join is found without depths: the tree is kept in PREORDER (pos[v], size[v], order[]), so
-//            "u is an ancestor of w" is pos[u] <= pos[w] < pos[u] + size[u];
+//   cycle    no climb: the tree is kept in PREORDER (pos[v], size[v], order[]), so "u is an ancestor of w" is
+//            pos[u] <= pos[w] < pos[u] + size[u], and the two tree paths from the entering arc's ends to their
+//            join are the nodes that are an ancestor of exactly one end -- every lane tests its share of the
+//            nodes (a first version climbed with two lanes: 1 us per hop of dependent L2 loads, 90 us per pivot);
 //   ratio    strict '<' on the side that loses flow first, '<=' on the other (the last blocking arc seen
 //            from the join leaves: strongly feasible trees, no cycling from a strongly feasible start);
 //   augment  all lanes over the two recorded paths;
@@ -19,7 +20,8 @@
 //            into 2k+1 pieces (k = path length) whose offsets telescope to old sizes, so every lane moves
 //            its elements of the affected range [lo, hi) of order[] independently (binary search over the
 //            path), shifts the potentials of S by the entering arc's reduced cost and rewrites pos[].
-// No thread/linked-list traversal anywhere: the sequential part of a pivot is the two climbs.
+// No pointer chasing anywhere in a pivot: every step is a flat pass of all lanes over nodes, path entries or a
+// range of the preorder array.
 //
 // Start: the given basis must be a spanning tree (vbasis 0 on V-1 arcs, cbasis 0 on the root row) whose tree
 // flows respect the bounds; anything else returns status 5 and the caller takes the general simplex
@@ -29,6 +31,7 @@
 #include "sx_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -46,6 +49,10 @@ struct NsShared { // results and flags, global memory
     int ntree;       // arcs coded basic
     int nroot;       // rows coded basic
     int root;
+    long long t_phase[8]; // shader clocks per phase, lane 0 (SX_NS_PROFILE=1 prints them)
+    long long blocks;     // pricing blocks scanned
+    long long path_sum;   // nodes on the cycles, all pivots
+    long long range_sum;  // preorder positions rewritten, all pivots
 };
 
 struct NsProblem {
@@ -62,7 +69,8 @@ struct NsProblem {
     int32_t *tmp;   // [V]
     int32_t *first_child, *next_sib; // [V] set-up only
     double *exc;    // [V] set-up only
-    int32_t *pnode[2], *parc[2], *ppos[2], *psize[2]; // [V] each: recorded paths of the two climbs
+    int32_t *pnode[2], *parc[2], *ppos[2], *psize[2]; // [V] each: the nodes of the two tree paths, as found
+    int32_t *snode, *sarc, *spos, *ssize;             // [V] each: the path u_in .. u_out in order
     int8_t *pdec[2];
     double *acc[2]; // [V] each: potentials refresh
     int32_t *anc[2];
@@ -131,21 +139,58 @@ __device__ __forceinline__ void ns_better(double &v, long long &e, double v2, lo
     }
 }
 
+// path lists in LDS (a tree path longer than this lives in the global lists only)
+constexpr int NS_PCAP = 1024;
+constexpr int NS_BITW = 8192; // 32-bit words of the position bitmap that LDS has room for (V <= 262144)
+// SMALL: the tree arrays (16 B per node) and the potentials (8 B) live in LDS for the whole solve
+constexpr int NS_SMALL_V = 4480;
+
+struct NsLists {
+    int node[2][NS_PCAP], arc[2][NS_PCAP], pos[2][NS_PCAP], size[2][NS_PCAP];
+    int8_t dec[2][NS_PCAP];
+    int snode[NS_PCAP], sarc[NS_PCAP], spos[NS_PCAP], ssize[NS_PCAP];
+};
+
+template <bool SMALL>
 __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_iters, double opt_tol, double feas_tol,
-                                                   int block_k) {
+                                                   int block_k, int use_bitmap) {
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    __shared__ NsLists L;
     __shared__ double s_v[NS_W];
     __shared__ long long s_e[NS_W];
     __shared__ double s_red[NS_W];
     __shared__ int s_flag;
     __shared__ int s_count;
-    __shared__ int s_k[2], s_arg[2], s_join[2];
-    __shared__ double s_delta[2];
+    __shared__ int s_k[2];
+    __shared__ int s_scan[NS_W];
+    __shared__ double s_bd[2][NS_W];
+    __shared__ int s_bsz[2][NS_W], s_bslot[2][NS_W];
+    __shared__ int s_in[4];     // entering arc: tail, head, state
+    __shared__ double s_inrc;   // its reduced cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = P.V;
     const long long E = P.E;
     NsShared *sh = P.sh;
-    volatile int4 *ndv = P.nd;
-    int4 *nd = P.nd;
+    int4 *nd;
+    double *y;
+    size_t dyn_off = 0;
+    if constexpr (SMALL) {
+        nd = reinterpret_cast<int4 *>(dyn_lds);
+        y = reinterpret_cast<double *>(dyn_lds + sizeof(int4) * static_cast<size_t>(V));
+        dyn_off = (sizeof(int4) + sizeof(double)) * static_cast<size_t>(V);
+    } else {
+        nd = P.nd;
+        y = P.y;
+    }
+    // bitmap over the preorder positions + prefix of its words' popcounts (ranks of the path nodes)
+    const int nwords = (V + 31) >> 5;
+    const int wpl = (nwords + NS_T - 1) / NS_T;
+    // (pointers into LDS are never tested against null: the flag says whether the room was allocated)
+    typedef __attribute__((address_space(3))) unsigned int lds_u32;
+    typedef __attribute__((address_space(3))) int lds_i32;
+    lds_u32 *bm = (lds_u32 *)(dyn_lds + dyn_off);
+    lds_i32 *wpre = (lds_i32 *)(dyn_lds + dyn_off + sizeof(unsigned int) * static_cast<size_t>(use_bitmap ? nwords : 0));
+    volatile int4 *ndv = nd;
 
     // ================================================================= set-up
     const int root = sh->root;
@@ -159,7 +204,7 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
     // tree arcs -> list (order irrelevant), in tmp
     for (long long e = tid; e < E; e += NS_T)
         if (P.state[e] == ST_TREE) {
-            const int slot = atomicAdd(&s_count, 1);
+            const int slot = __hip_atomic_fetch_add(&s_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < V) P.tmp[slot] = static_cast<int32_t>(e);
         }
     __syncthreads();
@@ -213,7 +258,7 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
         }
         int t = 0, v = root, infeasible = 0;
         double worst = 0.0;
-        P.y[root] = 0.0;
+        y[root] = 0.0;
         nd[root].z = 0;
         P.order[0] = root;
         P.exc[root] = P.beff[root];
@@ -224,7 +269,7 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
                 const int c = P.first_child[v];
                 if (c >= 0) { // enter the first child
                     const int a = nd[c].y;
-                    P.y[c] = (P.tail[a] == c) ? P.cost[a] + P.y[v] : P.y[v] - P.cost[a];
+                    y[c] = (P.tail[a] == c) ? P.cost[a] + y[v] : y[v] - P.cost[a];
                     nd[c].z = t;
                     P.order[t] = c;
                     P.exc[c] = P.beff[c];
@@ -247,15 +292,15 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
             f = f < 0.0 ? 0.0 : (f > cp ? cp : f);
             P.flow[a] = f;
             P.exc[par] = P.exc[par] + ex;
-            const int s = P.next_sib[v];
-            if (s >= 0) { // enter the next sibling
-                const int a2 = nd[s].y;
-                P.y[s] = (P.tail[a2] == s) ? P.cost[a2] + P.y[par] : P.y[par] - P.cost[a2];
-                nd[s].z = t;
-                P.order[t] = s;
-                P.exc[s] = P.beff[s];
+            const int sb = P.next_sib[v];
+            if (sb >= 0) { // enter the next sibling
+                const int a2 = nd[sb].y;
+                y[sb] = (P.tail[a2] == sb) ? P.cost[a2] + y[par] : y[par] - P.cost[a2];
+                nd[sb].z = t;
+                P.order[t] = sb;
+                P.exc[sb] = P.beff[sb];
                 ++t;
-                v = s;
+                v = sb;
                 down = true;
             } else {
                 v = par;
@@ -278,23 +323,41 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
     const long long B = static_cast<long long>(NS_T) * block_k;
     long long cursor = 0, scanned = 0, iters = 0;
     long long status = -1;
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nblocks = 0, path_sum = 0, range_sum = 0;
+    long long tc = clock64();
+    auto tick = [&](int k) {
+        const long long now = clock64();
+        tph[k] += now - tc;
+        tc = now;
+    };
     while (status < 0) {
-        // ---- price one block
-        double bv = 0.0;
+        ++nblocks;
+        // ---- price one block; the lane that holds the winner publishes the arc's data
+        double bv = 0.0, my_rc = 0.0;
         long long be = -1;
+        int my_p = 0, my_q = 0, my_st = 0;
         for (int k = 0; k < block_k; ++k) {
             long long e = cursor + tid + static_cast<long long>(k) * NS_T;
             if (e >= E) e -= E;
             if (e < E && static_cast<long long>(tid) + static_cast<long long>(k) * NS_T < E) {
                 const int st = P.state[e];
+                const int p = P.tail[e], q = P.head[e]; // requested with the state, not after it
+                const double ce = P.cost[e];
                 if (st != ST_TREE) {
-                    const int p = P.tail[e], q = P.head[e];
-                    const double rc = (P.cost[e] - P.y[p]) + P.y[q];
+                    const double rc = (ce - y[p]) + y[q];
                     const double viol = st == ST_LOWER ? -rc : rc;
-                    if (viol > opt_tol && p != q) ns_better(bv, be, viol, e);
+                    if (viol > opt_tol && p != q && (viol > bv || (viol == bv && (be < 0 || e < be)))) {
+                        bv = viol;
+                        be = e;
+                        my_p = p;
+                        my_q = q;
+                        my_st = st;
+                        my_rc = rc;
+                    }
                 }
             }
         }
+        const long long my_e = be;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double v2 = __shfl_down(bv, o, 64);
@@ -324,62 +387,132 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
             break;
         }
         ++iters;
+        if (my_e == be) {
+            s_in[0] = my_p;
+            s_in[1] = my_q;
+            s_in[2] = my_st;
+            s_inrc = my_rc;
+        }
+        if (tid < 2) s_k[tid] = 0;
+        __syncthreads();
+        tick(0);
 
-        // ---- cycle: climb from both ends of the entering arc to the join
+        // ---- cycle: every lane tests its nodes against the two ends of the entering arc.  In preorder "v is an
+        // ancestor of w" is pos[v] <= pos[w] < pos[v] + size[v], so the two tree paths to the join are the nodes
+        // that are an ancestor of exactly one end -- found by all lanes at once, no climb.  Sizes grow strictly
+        // along a path, so "first met from the end" is "smallest size".
         const long long ein = be;
-        const int p_in = P.tail[ein], q_in = P.head[ein];
-        const int st_in = P.state[ein];
-        const double rc_in = (P.cost[ein] - P.y[p_in]) + P.y[q_in];
+        const int p_in = s_in[0], q_in = s_in[1], st_in = s_in[2];
+        const double rc_in = s_inrc;
         const int first = st_in == ST_LOWER ? p_in : q_in; // the end that receives flow
         const int second = st_in == ST_LOWER ? q_in : p_in;
-        if (lane == 0 && wave < 2) {
-            const int side = wave;
-            const int start = side == 0 ? first : second, other = side == 0 ? second : first;
-            const int po = nd[other].z;
-            int k = 0, u = start, arg = -1;
-            double delta = INFINITY;
-            for (;;) {
-                const int4 r = nd[u];
-                if (r.z <= po && po < r.z + r.w) break; // u is an ancestor of (or is) the other end: the join
-                if (k >= V || r.x < 0) { // cannot happen on a tree: leave instead of spinning
-                    k = -1;
-                    break;
-                }
-                const int a = r.y;
-                const bool dec = (P.tail[a] == u) == (side == 0);
-                const double f = P.flow[a];
-                const double d = dec ? f : P.cap[a] - f;
-                P.pnode[side][k] = u;
-                P.parc[side][k] = a;
-                P.pdec[side][k] = dec ? 1 : 0;
-                P.ppos[side][k] = r.z;
-                P.psize[side][k] = r.w;
-                if (side == 0 ? (d < delta) : (d <= delta)) {
-                    delta = d;
-                    arg = k;
-                }
-                ++k;
-                u = r.x;
+        const int pf = nd[first].z, ps2 = nd[second].z;
+        const double cap_in = P.cap[ein];
+        double bd[2] = {INFINITY, INFINITY};
+        int bsz[2] = {0x7fffffff, -1}, bslot[2] = {-1, -1};
+        for (int base = 0; base < V; base += NS_T) { // uniform trip count: the slots come from wave ballots
+            const int v = base + tid;
+            const int4 r = nd[v < V ? v : V - 1]; // lanes past the end re-read the last node and stay out
+            const bool a1 = r.z <= pf && pf < r.z + r.w, a2 = r.z <= ps2 && ps2 < r.z + r.w;
+            const bool on = v < V && a1 != a2;
+            const int side = a1 ? 0 : 1;
+            const unsigned long long m0 = __ballot(on && side == 0), m1 = __ballot(on && side == 1);
+            int base0 = 0, base1 = 0;
+            int cnt0 = __popcll(m0), cnt1 = __popcll(m1);
+            asm volatile("" : "+v"(cnt0), "+v"(cnt1)); // the counts are wave-uniform: keep them in VGPRs for ds_add
+            if (lane == 0) { // one LDS atomic per wave and side instead of one per path node
+                if (cnt0) base0 = __hip_atomic_fetch_add(&s_k[0], cnt0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cnt1) base1 = __hip_atomic_fetch_add(&s_k[1], cnt1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            s_k[side] = k;
-            s_arg[side] = arg;
-            s_delta[side] = delta;
-            s_join[side] = u;
+            base0 = __builtin_amdgcn_readfirstlane(base0);
+            base1 = __builtin_amdgcn_readfirstlane(base1);
+            if (on) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int slot = side == 0 ? base0 + __popcll(m0 & below) : base1 + __popcll(m1 & below);
+                if (slot < NS_PCAP) { // global memory takes only what LDS has no room for
+                    L.node[side][slot] = v;
+                    L.arc[side][slot] = r.y;
+                    L.pos[side][slot] = r.z;
+                    L.size[side][slot] = r.w;
+                } else {
+                    P.pnode[side][slot] = v;
+                    P.parc[side][slot] = r.y;
+                    P.ppos[side][slot] = r.z;
+                    P.psize[side][slot] = r.w;
+                }
+            }
         }
         __syncthreads();
-        if (s_k[0] < 0 || s_k[1] < 0 || s_join[0] != s_join[1]) {
-            status = 4;
-            break;
+        // the arcs of the two paths: residual in the direction of the cycle, ratio test -- one entry per lane, so
+        // the arc data of the whole cycle arrive in one round trip
+        {
+            const int k0 = s_k[0], k1 = s_k[1];
+            for (int i = tid; i < k0 + k1; i += NS_T) {
+                const int side = i < k0 ? 0 : 1, j = i < k0 ? i : i - k0;
+                const bool in_lds = j < NS_PCAP;
+                const int v = in_lds ? L.node[side][j] : P.pnode[side][j];
+                const int a = in_lds ? L.arc[side][j] : P.parc[side][j];
+                const int sz = in_lds ? L.size[side][j] : P.psize[side][j];
+                const bool dec = (P.tail[a] == v) == (side == 0);
+                const double f = P.flow[a];
+                const double d = dec ? f : P.cap[a] - f;
+                if (in_lds) L.dec[side][j] = dec ? 1 : 0;
+                else P.pdec[side][j] = dec ? 1 : 0;
+                // ratio test: strict on the first side (first blocking arc from the end), the last one on the second
+                if (side == 0 ? (d < bd[0] || (d == bd[0] && sz < bsz[0])) : (d < bd[1] || (d == bd[1] && sz > bsz[1]))) {
+                    bd[side] = d;
+                    bsz[side] = sz;
+                    bslot[side] = j;
+                }
+            }
         }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const double d2 = __shfl_down(bd[sd], o2, 64);
+                const int z2 = __shfl_down(bsz[sd], o2, 64), l2 = __shfl_down(bslot[sd], o2, 64);
+                if (l2 >= 0 && (bslot[sd] < 0 || d2 < bd[sd] || (d2 == bd[sd] && (sd == 0 ? z2 < bsz[sd] : z2 > bsz[sd])))) {
+                    bd[sd] = d2;
+                    bsz[sd] = z2;
+                    bslot[sd] = l2;
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                s_bd[sd][wave] = bd[sd];
+                s_bsz[sd][wave] = bsz[sd];
+                s_bslot[sd][wave] = bslot[sd];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            bd[sd] = s_bd[sd][0];
+            bsz[sd] = s_bsz[sd][0];
+            bslot[sd] = s_bslot[sd][0];
+            for (int w = 1; w < NS_W; ++w) {
+                const double d2 = s_bd[sd][w];
+                const int z2 = s_bsz[sd][w], l2 = s_bslot[sd][w];
+                if (l2 >= 0 && (bslot[sd] < 0 || d2 < bd[sd] || (d2 == bd[sd] && (sd == 0 ? z2 < bsz[sd] : z2 > bsz[sd])))) {
+                    bd[sd] = d2;
+                    bsz[sd] = z2;
+                    bslot[sd] = l2;
+                }
+            }
+        }
+        tick(1);
         // ---- ratio test
-        double delta = P.cap[ein];
+        double delta = cap_in;
         int result = 0;
-        if (s_delta[0] < delta) {
-            delta = s_delta[0];
+        if (bslot[0] >= 0 && bd[0] < delta) {
+            delta = bd[0];
             result = 1;
         }
-        if (s_delta[1] <= delta) {
-            delta = s_delta[1];
+        if (bslot[1] >= 0 && bd[1] <= delta) {
+            delta = bd[1];
             result = 2;
         }
         if (isinf(delta)) {
@@ -388,58 +521,144 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
         }
         // ---- augment
         const int k0 = s_k[0], k1 = s_k[1];
-        if (delta > 0.0) {
-            for (int i = tid; i < k0 + k1; i += NS_T) {
-                const int side = i < k0 ? 0 : 1, j = i < k0 ? i : i - k0;
-                const int a = P.parc[side][j];
-                P.flow[a] = P.pdec[side][j] ? P.flow[a] - delta : P.flow[a] + delta;
+        path_sum += k0 + k1;
+        auto e_node = [&](int side, int j) { return j < NS_PCAP ? L.node[side][j] : P.pnode[side][j]; };
+        auto e_arc = [&](int side, int j) { return j < NS_PCAP ? L.arc[side][j] : P.parc[side][j]; };
+        auto e_pos = [&](int side, int j) { return j < NS_PCAP ? L.pos[side][j] : P.ppos[side][j]; };
+        auto e_size = [&](int side, int j) { return j < NS_PCAP ? L.size[side][j] : P.psize[side][j]; };
+        auto e_dec = [&](int side, int j) { return j < NS_PCAP ? L.dec[side][j] : P.pdec[side][j]; };
+        const int s = result - 1, o = 1 - s; // (s = -1: the entering arc itself blocks)
+        const int out_slot = result ? bslot[s] : -1;
+        for (int i = tid; i < k0 + k1; i += NS_T) {
+            const int side = i < k0 ? 0 : 1, j = i < k0 ? i : i - k0;
+            const int a = e_arc(side, j);
+            const bool dec = e_dec(side, j) != 0;
+            if (side == s && j == out_slot) { // the leaving arc lands exactly on its bound
+                P.flow[a] = dec ? 0.0 : P.cap[a];
+                P.state[a] = static_cast<int8_t>(dec ? ST_LOWER : ST_UPPER);
+            } else if (delta > 0.0) {
+                P.flow[a] = dec ? P.flow[a] - delta : P.flow[a] + delta;
             }
         }
         if (result == 0) { // the entering arc runs to its other bound: no change of the tree
             if (tid == 0) {
                 P.state[ein] = static_cast<int8_t>(-st_in);
-                P.flow[ein] = st_in == ST_LOWER ? P.cap[ein] : 0.0;
+                P.flow[ein] = st_in == ST_LOWER ? cap_in : 0.0;
             }
             __syncthreads();
             continue;
         }
-        const int s = result - 1, o = 1 - s;
-        const int idx = s_arg[s];
+        tick(2);
         const int ks = s_k[s], ko = s_k[o];
         const int u_in = s == 0 ? first : second, v_in = s == 0 ? second : first;
-        const int n_sub = P.psize[s][idx], a_pos = P.ppos[s][idx];
-        const int b_pos = nd[v_in].z;
+        const int n_sub = bsz[s], a_pos = e_pos(s, out_slot);
+        const int b_pos = s == 0 ? ps2 : pf;
         const double dy = (p_in == u_in) ? rc_in : -rc_in;
-        __syncthreads(); // every lane has read the flows / records it needs
         if (tid == 0) {
-            const int a_out = P.parc[s][idx];
-            const bool dec = P.pdec[s][idx] != 0;
-            P.state[a_out] = static_cast<int8_t>(dec ? ST_LOWER : ST_UPPER);
-            P.flow[a_out] = dec ? 0.0 : P.cap[a_out];
             P.state[ein] = ST_TREE;
-            P.flow[ein] = st_in == ST_LOWER ? delta : P.cap[ein] - delta;
+            P.flow[ein] = st_in == ST_LOWER ? delta : cap_in - delta;
+            s_count = 0;
         }
-        // ---- sizes off the old branch, onto the new one; the path itself is re-rooted
+        __syncthreads();
+        auto put_sorted = [&](int rank, int node, int arc, int ps, int sz) {
+            if (rank < NS_PCAP) {
+                L.snode[rank] = node;
+                L.sarc[rank] = arc;
+                L.spos[rank] = ps;
+                L.ssize[rank] = sz;
+            } else {
+                P.snode[rank] = node;
+                P.sarc[rank] = arc;
+                P.spos[rank] = ps;
+                P.ssize[rank] = sz;
+            }
+        };
+        auto s_node = [&](int i) { return i < NS_PCAP ? L.snode[i] : P.snode[i]; };
+        auto s_arc = [&](int i) { return i < NS_PCAP ? L.sarc[i] : P.sarc[i]; };
+        auto s_pos = [&](int i) { return i < NS_PCAP ? L.spos[i] : P.spos[i]; };
+        auto s_size = [&](int i) { return i < NS_PCAP ? L.ssize[i] : P.ssize[i]; };
+        // ---- the path u_in .. u_out in order (the rest of side s, above u_out, loses the subtree; the other side
+        // gains it).  Order = by position: a bitmap over the preorder positions takes the path's nodes, popcounts
+        // give every node its rank (without the bitmap, V > 32 * NS_BITW: by counting, k^2 / lanes)
+        if (use_bitmap) {
+            for (int w = tid; w < nwords; w += NS_T) bm[w] = 0u;
+            __syncthreads();
+        }
         for (int i = tid; i < ks + ko; i += NS_T) {
             if (i < ks) {
-                const int w = P.pnode[s][i];
-                if (i > idx) {
-                    nd[w].w = P.psize[s][i] - n_sub;
+                const int sz = e_size(s, i);
+                if (sz > n_sub) {
+                    nd[e_node(s, i)].w = sz - n_sub;
+                } else if (use_bitmap) {
+                    const int ps = e_pos(s, i);
+                    __atomic_fetch_or(&bm[ps >> 5], 1u << (ps & 31), __ATOMIC_RELAXED);
                 } else {
-                    nd[w].x = i == 0 ? v_in : P.pnode[s][i - 1];
-                    nd[w].y = i == 0 ? static_cast<int>(ein) : P.parc[s][i - 1];
-                    nd[w].w = i == 0 ? n_sub : n_sub - P.psize[s][i - 1];
+                    int rank = 0;
+                    for (int j = 0; j < ks; ++j) rank += e_size(s, j) < sz ? 1 : 0;
+                    put_sorted(rank, e_node(s, i), e_arc(s, i), e_pos(s, i), sz);
+                    __hip_atomic_fetch_add(&s_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else {
                 const int j = i - ks;
-                nd[P.pnode[o][j]].w = P.psize[o][j] + n_sub;
+                nd[e_node(o, j)].w = e_size(o, j) + n_sub;
             }
+        }
+        __syncthreads();
+        if (use_bitmap) {
+            // exclusive prefix of the words' popcounts (lane t owns words [t * wpl, (t + 1) * wpl))
+            int local = 0;
+            for (int q = 0; q < wpl; ++q) {
+                const int w = tid * wpl + q;
+                if (w < nwords) local += __popc(bm[w]);
+            }
+            int incl = local;
+#pragma unroll
+            for (int d2 = 1; d2 < 64; d2 <<= 1) {
+                const int up = __shfl_up(incl, d2, 64);
+                if (lane >= d2) incl += up;
+            }
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < NS_W; ++w) {
+                before += w < wave ? s_scan[w] : 0;
+                total += s_scan[w];
+            }
+            int run = before + incl - local;
+            for (int q = 0; q < wpl; ++q) {
+                const int w = tid * wpl + q;
+                if (w < nwords) {
+                    wpre[w] = run;
+                    run += __popc(bm[w]);
+                }
+            }
+            if (tid == 0) s_count = total;
+            __syncthreads();
+            for (int i = tid; i < ks; i += NS_T) {
+                const int sz = e_size(s, i);
+                if (sz <= n_sub) {
+                    const int ps = e_pos(s, i);
+                    const int above = wpre[ps >> 5] + __popc(bm[ps >> 5] & ((1u << (ps & 31)) - 1u));
+                    const int rank = total - 1 - above; // deepest node (u_in) first
+                    put_sorted(rank, e_node(s, i), e_arc(s, i), ps, sz);
+                }
+            }
+            __syncthreads();
+        }
+        tick(3);
+        const int idx = s_count - 1; // position of u_out on the path
+        // the path is re-rooted: every node hangs under its former child
+        for (int i = tid; i <= idx; i += NS_T) {
+            const int w = s_node(i);
+            nd[w].x = i == 0 ? v_in : s_node(i - 1);
+            nd[w].y = i == 0 ? static_cast<int>(ein) : s_arc(i - 1);
+            nd[w].w = i == 0 ? n_sub : n_sub - s_size(i - 1);
         }
         // ---- preorder: S (old [a_pos, a_pos + n_sub)) moves right behind v_in, re-rooted at u_in
         const int lo = a_pos < b_pos + 1 ? a_pos : b_pos + 1;
         const int hi = a_pos + n_sub > b_pos + 1 ? a_pos + n_sub : b_pos + 1;
         const int newstart = b_pos < a_pos ? b_pos + 1 : b_pos + 1 - n_sub;
-        const int32_t *pp = P.ppos[s], *ps = P.psize[s];
+        range_sum += hi - lo;
         for (int t = lo + tid; t < hi; t += NS_T) {
             const int w = P.order[t];
             int nt;
@@ -447,33 +666,35 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
                 int l2 = 0, h2 = idx; // smallest i with t inside the old segment of path node i
                 while (l2 < h2) {
                     const int mid = (l2 + h2) >> 1;
-                    const int q0 = pp[mid];
-                    if (t >= q0 && t < q0 + ps[mid]) h2 = mid;
+                    const int q0 = s_pos(mid);
+                    if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
                     else l2 = mid + 1;
                 }
                 const int i = l2;
                 int rel, off = 0;
                 if (i == 0) {
-                    rel = t - pp[0];
+                    rel = t - s_pos(0);
                 } else {
-                    const int hp = pp[i - 1], hs = ps[i - 1]; // the hole: the old segment of path node i-1
+                    const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i-1
                     off = hs;
-                    rel = t < hp ? t - pp[i] : (hp - pp[i]) + (t - (hp + hs));
+                    rel = t < hp ? t - s_pos(i) : (hp - s_pos(i)) + (t - (hp + hs));
                 }
                 nt = newstart + off + rel;
-                P.y[w] = P.y[w] + dy;
+                y[w] = y[w] + dy;
             } else {
                 nt = b_pos < a_pos ? t + n_sub : t - n_sub;
             }
             P.tmp[nt - lo] = w;
         }
         __syncthreads();
+        tick(4);
         for (int t = lo + tid; t < hi; t += NS_T) {
             const int w = P.tmp[t - lo];
             P.order[t] = w;
             nd[w].z = t;
         }
         __syncthreads();
+        tick(5);
     }
 
     // ================================================================= results
@@ -525,6 +746,10 @@ __global__ __launch_bounds__(NS_T) void k_ns_solve(NsProblem P, long long max_it
         sh->obj = tot;
         sh->iters = iters;
         sh->status = status;
+        for (int k = 0; k < 8; ++k) sh->t_phase[k] = tph[k];
+        sh->blocks = nblocks;
+        sh->path_sum = path_sum;
+        sh->range_sum = range_sum;
     }
 }
 
@@ -565,6 +790,7 @@ SX_API int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
     const int64_t V = A->m, E = A->n;
     if (V < 2 || E < 1 || V >= (static_cast<int64_t>(1) << 30) || E >= (static_cast<int64_t>(1) << 31) || A->nnz != 2 * E)
         return SX_OK; // not a network: the caller takes the general simplex
+    if (ctx->opt_netsimplex == 0) return SX_OK;
     hipStream_t s = ctx->stream;
     Pool pool;
     NsProblem P;
@@ -605,6 +831,10 @@ SX_API int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
     SX_TRY(pool.get(V, &P.first_child));
     SX_TRY(pool.get(V, &P.next_sib));
     SX_TRY(pool.get(V, &P.exc));
+    SX_TRY(pool.get(V, &P.snode));
+    SX_TRY(pool.get(V, &P.sarc));
+    SX_TRY(pool.get(V, &P.spos));
+    SX_TRY(pool.get(V, &P.ssize));
     for (int k = 0; k < 2; ++k) {
         SX_TRY(pool.get(V, &P.pnode[k]));
         SX_TRY(pool.get(V, &P.parc[k]));
@@ -620,12 +850,29 @@ SX_API int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
     block_k = block_k < 1 ? 1 : block_k > 8 ? 8 : block_k;
     if (ctx->opt_ns_block > 0) block_k = ctx->opt_ns_block > 64 ? 64 : ctx->opt_ns_block;
     const long long limit = max_iter > 0 ? max_iter : 100 * (V + E);
-    hipLaunchKernelGGL(k_ns_solve, dim3(1), dim3(NS_T), 0, s, P, limit, opt_tol, feas_tol, block_k);
+    const int64_t nwords = (V + 31) / 32;
+    const int use_bitmap = nwords <= NS_BITW ? 1 : 0;
+    const size_t bm_bytes = use_bitmap ? static_cast<size_t>(nwords) * 8 : 0;
+    if (V <= NS_SMALL_V && ctx->opt_ns_lds) { // tree and potentials in LDS
+        const size_t dyn = (sizeof(int4) + sizeof(double)) * static_cast<size_t>(V) + bm_bytes;
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ns_solve<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn)));
+        hipLaunchKernelGGL(k_ns_solve<true>, dim3(1), dim3(NS_T), dyn, s, P, limit, opt_tol, feas_tol, block_k, use_bitmap);
+    } else {
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ns_solve<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bm_bytes)));
+        hipLaunchKernelGGL(k_ns_solve<false>, dim3(1), dim3(NS_T), bm_bytes, s, P, limit, opt_tol, feas_tol, block_k,
+                           use_bitmap);
+    }
     hipLaunchKernelGGL(k_ns_outputs, dim3(static_cast<unsigned>(((E > V ? E : V) + 255) / 256)), dim3(256), 0, s, V, E,
                        state, sh.root, vbasis_out, cbasis_out);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
+    if (getenv("SX_NS_PROFILE"))
+        fprintf(stderr, "[sx_netsimplex] V=%lld E=%lld pivots=%lld blocks=%lld clocks: price %lld mark %lld augment %lld rank %lld "
+                        "range1 %lld range2 %lld; cycle nodes %lld, positions moved %lld\n", (long long)V, (long long)E, sh.iters, sh.blocks,
+                sh.t_phase[0], sh.t_phase[1], sh.t_phase[2], sh.t_phase[3], sh.t_phase[4], sh.t_phase[5], sh.path_sum, sh.range_sum);
     result->status = sh.status;
     result->iters = sh.iters;
     result->phase1_iters = 0;
