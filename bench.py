@@ -225,6 +225,37 @@ def crossover_network():
     return out
 
 
+def crossover_mcf(V: int = 4096, E: int = 32768):
+    """BASELINE metric, part 'crossover wall-time (ms)', min-cost-flow case: the whole ``network_crossover`` call
+    (CNET_MCF) on a V-node / E-arc network of config 4's family, once with the re-solves on the device (solver
+    'HIP': every round is a network LP with a warm tree basis -> network simplex K16n) and once in HiGHS on the
+    host cores.  Config 4 itself (V = 2^17, E = 2^20) is in profiles/r02/network_simplex.md: 94 s with HiGHS,
+    not finished after 18 minutes on the device."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import MinCostFlow
+    from smart_crossover.network_methods.algorithms import network_crossover
+    out = {"workload": f"min-cost flow V = {V}, E = {E} (workloads.mcf, seed 3), method cnet_mcf, host memory to host memory"}
+    costs = {}
+    for solver, key in (("HIP", "gpu_resident_ms"), ("HGS", "host_solver_ms")):
+        times = []
+        for _ in range(2):
+            inst = workloads.mcf(V, E, 3)
+            mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
+            t0 = time.perf_counter()
+            with redirect_stdout(io.StringIO()):
+                res = network_crossover(inst.x.copy(), mcf=mcf, method="cnet_mcf", solver=solver)
+            times.append((time.perf_counter() - t0) * 1e3)
+        costs[solver] = float(inst.c @ res.x[:E])
+        out[key] = float(times[-1])
+        out[f"simplex_iterations_{solver}"] = int(res.iter_count)
+    if abs(costs["HIP"] - costs["HGS"]) > 1e-9 * (1 + abs(costs["HGS"])):
+        raise SystemExit("bench: device and HiGHS re-solves disagree on the optimal flow cost")
+    out["optimal_cost"] = costs["HGS"]
+    out["speedup"] = out["host_solver_ms"] / out["gpu_resident_ms"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -550,7 +581,8 @@ def main():
         crossover = {"lp_c2_host_path": crossover_host_path(args.cpu_seconds),
                      "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
                      "lp_c5_get_perturb_problem": crossover_lp_c5(),
-                     "network_c3": crossover_network()}
+                     "network_c3": crossover_network(),
+                     "network_mcf_4096": crossover_mcf()}
 
     if rank == 0:
         out = {
