@@ -68,7 +68,7 @@ def crossover_host_path(cpu_budget_s: float):
     lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
     times = []
     mgr = None
-    for _ in range(3):                      # first call uploads the matrix; report the steady state too
+    for _ in range(5):                      # first call uploads the matrix; report the steady state too
         t0 = time.perf_counter()
         with redirect_stdout(io.StringIO()):
             mgr = get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
@@ -256,7 +256,22 @@ def crossover_mcf(V: int = 4096, E: int = 32768):
     return out
 
 
+def _heartbeat():
+    """One stderr line a minute while the long legs (HiGHS beside the device crossover) run: a driver that takes
+    minutes of silence for a hang sees progress.  stdout stays the single JSON line."""
+    import threading
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print(f"[bench] running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    threading.Thread(target=beat, daemon=True).start()
+
+
 def main():
+    _heartbeat()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -578,11 +593,12 @@ def main():
         if uniform is None:             # free the resident c5 shard before the crossovers allocate theirs
             for a in (dC, dR):
                 a.free()
+        net_c3, net_mcf = crossover_network(), crossover_mcf()
         crossover = {"lp_c2_host_path": crossover_host_path(args.cpu_seconds),
                      "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
                      "lp_c5_get_perturb_problem": crossover_lp_c5(),
-                     "network_c3": crossover_network(),
-                     "network_mcf_4096": crossover_mcf()}
+                     "network_c3": net_c3,
+                     "network_mcf_4096": net_mcf}
 
     if rank == 0:
         out = {
