@@ -77,7 +77,11 @@ int sx_ctx_sync(sx_ctx *ctx);
  * "rowblock" (column-blocked copy of the rows for the row walk of sx_score_rows and the projector CG:
  * -1 auto [default: built on first use for matrices of >= 4M entries when at least half of them fall into
  * column blocks dense enough for an LDS window], 0 off, 1 whenever the matrix admits it; results are
- * bit-identical either way -- a matrix with a row whose column indices descend somewhere keeps the plain walk).
+ * bit-identical either way -- a matrix with a row whose column indices descend somewhere keeps the plain walk),
+ * "netsimplex" (sx_netsimplex_dev: -1 / 1 = run whenever problem and basis are in its domain [default],
+ * 0 = always answer status 5, i.e. send network re-solves to the general simplex), "ns_lds" (0/1, default 1:
+ * tree arrays and potentials of the network simplex in LDS when they fit, V <= 4480), "ns_block" (arcs priced
+ * per lane and block by the network simplex: 0 = by size [default], 1..64).
  * Unknown keys return SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
