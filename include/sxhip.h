@@ -81,7 +81,9 @@ int sx_ctx_sync(sx_ctx *ctx);
  * "netsimplex" (sx_netsimplex_dev: -1 / 1 = run whenever problem and basis are in its domain [default],
  * 0 = always answer status 5, i.e. send network re-solves to the general simplex), "ns_lds" (0/1, default 1:
  * tree arrays and potentials of the network simplex in LDS when they fit, V <= 4480), "ns_block" (arcs priced
- * per lane and block by the network simplex: 0 = by size [default], 1..64).
+ * per lane and block by the network simplex: 0 = by size [default], 1..64), "netdual" (sx_netdual_dev: -1 / 1 =
+ * run whenever problem and basis are in its domain [default], 0 = always answer status 5) and "nd_grid"
+ * (workgroups of its cooperative grid: 0 = by size [default], 1..256).
  * Unknown keys return SX_ERR_INVALID. */
 int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value);
 /* name (e.g. "gfx950:sramecc+:xnack-"), CU count and total HBM bytes of the context's device */
@@ -411,6 +413,21 @@ int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const do
                       const double *u, const int8_t *vbasis_in, const int8_t *cbasis_in, int64_t max_iter,
                       double feas_tol, double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
                       sx_simplex_result *result);
+
+/* Dual network simplex (K16d) for the same re-solves, the whole GPU on one pivot (csrc/sx_netdual.hip; algorithm
+ * stated in oracle/net_simplex.py).  Domain: A a node-arc incidence matrix as above, l = 0, (vbasis_in, cbasis_in)
+ * a spanning tree -- it need NOT be primal feasible -- and every non-tree arc whose reduced cost has the wrong
+ * sign for its bound must have a finite capacity (it is moved to its other bound, which makes the tree dual
+ * feasible).  That is the situation of every column-generation round of the network crossover: the previous
+ * round's optimal tree plus new arcs at a bound (network_methods/algorithms.py:109-140).  Then: dual simplex on
+ * the tree in preorder arrays, leaving arc by exact dual steepest edge (violation^2 / subtree size), bound-flipping
+ * ratio test over the arcs of the cut, a cooperative grid of workgroups sharing every pass.  result->status:
+ * 0 optimal, 1 primal infeasible, 3 iteration limit, 5 outside the domain (nothing solved: take
+ * sx_netsimplex_dev / sx_simplex_solve_dev); result->phase1_iters counts the arcs moved bound to bound.
+ * Outputs as sx_simplex_solve_dev.  Blocking; arrays device. */
+int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                   const double *u, const int8_t *vbasis_in, const int8_t *cbasis_in, int64_t max_iter,
+                   double feas_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
 
 /* ------------------------------------------------------------------ entropic OT warm start
  * The step before the OT crossover in the reference's driver (scripts/run_network_crossover.py:95-97:

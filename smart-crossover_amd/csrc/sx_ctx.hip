@@ -97,6 +97,12 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "netsimplex")) {
         SX_REQUIRE(value >= -1 && value <= 1, "netsimplex must be -1 (by size), 0 (off) or 1 (whenever it applies)");
         ctx->opt_netsimplex = static_cast<int>(value);
+    } else if (!strcmp(key, "netdual")) {
+        SX_REQUIRE(value >= -1 && value <= 1, "netdual must be -1 / 1 (whenever it applies) or 0 (off)");
+        ctx->opt_netdual = static_cast<int>(value);
+    } else if (!strcmp(key, "nd_grid")) {
+        SX_REQUIRE(value >= 0 && value <= 256, "nd_grid must be 0 (by size) or 1..256 workgroups");
+        ctx->opt_nd_grid = static_cast<int>(value);
     } else if (!strcmp(key, "ns_lds")) {
         ctx->opt_ns_lds = value ? 1 : 0;
     } else if (!strcmp(key, "ns_block")) {

@@ -78,6 +78,8 @@ struct sx_ctx {
     int opt_netsimplex = -1; // K16n for network re-solves: -1 by size, 0 never (general simplex), 1 whenever it applies
     int opt_ns_lds = 1;      // K16n: tree arrays and potentials in LDS when they fit (V <= 4608)
     int opt_ns_block = 0;    // K16n network simplex: arcs priced per lane and block (0: by size, 1..64)
+    int opt_netdual = -1;    // K16d dual network simplex on the whole GPU: -1 / 1 whenever it applies, 0 never
+    int opt_nd_grid = 0;     // K16d: workgroups of its cooperative grid (0: by size)
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
 };
 

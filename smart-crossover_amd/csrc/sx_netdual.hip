@@ -1,0 +1,945 @@
+// K16d: DUAL network simplex on a spanning-tree basis, the whole GPU on one pivot -- the re-solves of the
+// network crossover's column generation (network_methods/net_manager.py:211-222 solve_subproblem ->
+// solve_mcf(..., warm_start_basis); network_methods/algorithms.py:109-140).
+//
+// Why dual: a round of the column generation adds thousands of arcs, all sitting at a bound, to a problem whose
+// tree was optimal.  The tree stays dual feasible once every new arc with a wrong-signed reduced cost is moved to
+// its other bound (capacities are finite), so the dual method starts at once, and its bound-flipping ratio test
+// moves many arcs per iteration; the primal method (sx_netsimplex.hip) has to bring them in one by one and takes
+// 3-6x the iterations on those rounds (profiles/r02/network_simplex.md).  oracle/net_simplex.py states the
+// algorithm; on integral data device and oracle make the same pivots.
+//
+// Why the whole GPU: with the tree in PREORDER (pos, size, order) every step of an iteration is a flat pass --
+//   leaving    tree arc with the largest violation^2 / |subtree| (|subtree| = squared norm of the arc's row of
+//              the basis inverse: exact dual steepest edge for free), all nodes, two-level reduction
+//   cut        arcs with exactly one end in the subtree S = [pos, pos + size): the adjacency (CSR rows) of S's
+//              nodes when S is small, all arcs otherwise; candidates -> list
+//   ratio      ascending |reduced cost|: arcs are passed (flipped) while the flips leave the leaving arc
+//              infeasible, the next one enters (one workgroup, a few reductions)
+//   update     potentials of S, flows of the tree arcs whose subtree separates the ends of a moved arc, subtree
+//              sizes above the two attachment points: all nodes, no climbing
+//   re-hang    S re-rooted at the entering arc: its path to the old root in order (ordered compaction by
+//              position), then every element of the affected range of order[] is placed independently
+// -- and at config 4 (131,073 nodes, 1e6 arcs) one workgroup needs 340 us for such passes.  Here a cooperative
+// grid of workgroups shares them, six grid barriers per iteration.  Deterministic: no floating-point atomics,
+// fixed reduction orders, ties by index.
+#include "sx_internal.h"
+
+#include <hip/hip_cooperative_groups.h>
+
+#include <cmath>
+#include <cstdlib>
+
+namespace cg = cooperative_groups;
+
+namespace {
+
+constexpr int ND_T = 1024;       // lanes per workgroup
+constexpr int ND_W = ND_T / 64;  // waves per workgroup
+constexpr int ND_GMAX = 256;     // workgroups of the cooperative grid (one per CU at most)
+constexpr int ND_PATH_LDS = 2048; // path entries cached in LDS for the preorder move
+constexpr int ST_TREE = 0, ST_LOWER = 1, ST_UPPER = -1;
+constexpr int UNK = -2;
+
+struct NdIter { // the iteration's decisions: written by workgroup 0, read by all
+    int enter;      // entering arc, -1: none (primal infeasible)
+    int u_in, v_in; // its end inside / outside the subtree
+    int p_uin;      // pos[u_in]
+    int b_pos;      // pos[v_in]
+    int npush;      // moved arcs: the passed ones and, last, the entering arc
+    double theta;   // |reduced cost| of the entering arc
+};
+
+struct NdShared {
+    long long iters;
+    long long status; // 0 optimal, 1 primal infeasible, 3 iteration limit, 5 not applicable
+    long long flips;
+    double obj;
+    double max_violation;
+    int not_network;
+    int ntree, nroot, root;
+    int cand_count;
+    int pad_;
+    NdIter it;
+};
+
+struct NdProblem {
+    int V;
+    long long E;
+    int G; // workgroups
+    const int64_t *rowptr; // CSR of A: row v -> its arcs
+    const int32_t *rowarc;
+    int32_t *tail, *head;
+    const double *cost, *cap;
+    double *flow;
+    int8_t *state;
+    int4 *nd;       // {parent, pred arc, pos, size}
+    double *y;
+    int32_t *order, *tmp;
+    int32_t *first_child, *next_sib; // set-up
+    double *e, *bsum;                // set-up: b - A x_N in preorder, block sums
+    // per iteration
+    double *part_s;
+    int *part_n;
+    int *part_cnt;
+    int32_t *cand_j;
+    double *cand_r, *cand_c;
+    int32_t *push_pt, *push_ph;
+    double *push_d;
+    int32_t *snode, *sarc, *spos, *ssize;
+    double *acc[2];
+    int32_t *anc[2];
+    NdShared *sh;
+};
+
+// ------------------------------------------------------------------ arcs from the columns of A
+__global__ __launch_bounds__(256) void k_nd_endpoints(int64_t E, const int64_t *__restrict__ colptr,
+                                                      const int32_t *__restrict__ rowidx,
+                                                      const double *__restrict__ val, const double *__restrict__ l,
+                                                      const double *__restrict__ u, const int8_t *__restrict__ vbasis,
+                                                      int32_t *__restrict__ tail, int32_t *__restrict__ head,
+                                                      int8_t *__restrict__ state, NdShared *sh) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= E) return;
+    const int64_t p0 = colptr[j];
+    bool ok = colptr[j + 1] - p0 == 2 && l[j] == 0.0 && u[j] >= 0.0;
+    int t = 0, h = 0;
+    if (ok) {
+        const double a = val[p0], b = val[p0 + 1];
+        if (a == 1.0 && b == -1.0) {
+            t = rowidx[p0];
+            h = rowidx[p0 + 1];
+        } else if (a == -1.0 && b == 1.0) {
+            t = rowidx[p0 + 1];
+            h = rowidx[p0];
+        } else {
+            ok = false;
+        }
+    }
+    const int code = vbasis[j];
+    const int st = code == 0 ? ST_TREE : code == -2 ? ST_UPPER : ST_LOWER;
+    if (code != 0 && code != -1 && code != -2) ok = false;
+    if (st == ST_UPPER && isinf(u[j])) ok = false;
+    tail[j] = t;
+    head[j] = h;
+    state[j] = static_cast<int8_t>(st);
+    if (!ok) sh->not_network = 1;
+    if (st == ST_TREE) atomicAdd(&sh->ntree, 1);
+}
+
+__global__ __launch_bounds__(256) void k_nd_root(int64_t V, const int8_t *__restrict__ cbasis, NdShared *sh) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= V) return;
+    if (cbasis[i] == 0) {
+        atomicAdd(&sh->nroot, 1);
+        sh->root = static_cast<int>(i);
+    }
+}
+
+// ------------------------------------------------------------------ set-up: tree arrays, preorder, potentials
+// one workgroup: parents by hooking sweeps from the root, children in ascending node order, one depth-first pass
+__global__ __launch_bounds__(ND_T) void k_nd_tree(NdProblem P) {
+    __shared__ int s_flag, s_count;
+    const int tid = threadIdx.x;
+    const int V = P.V;
+    const long long E = P.E;
+    NdShared *sh = P.sh;
+    int4 *nd = P.nd;
+    volatile int4 *ndv = nd;
+    const int root = sh->root;
+    for (int v = tid; v < V; v += ND_T) {
+        nd[v] = make_int4(v == root ? -1 : UNK, -1, 0, 1);
+        P.first_child[v] = -1;
+        P.next_sib[v] = -1;
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (long long e = tid; e < E; e += ND_T)
+        if (P.state[e] == ST_TREE) {
+            const int slot = __hip_atomic_fetch_add(&s_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < V) P.tmp[slot] = static_cast<int32_t>(e);
+        }
+    __syncthreads();
+    const int ntree = s_count;
+    for (int sweep = 0; sweep <= V; ++sweep) {
+        __syncthreads();
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < ntree; i += ND_T) {
+            const int e = P.tmp[i];
+            const int p = P.tail[e], q = P.head[e];
+            const int pp = ndv[p].x, pq = ndv[q].x;
+            if (pp != UNK && pq == UNK) {
+                ndv[q].x = p;
+                ndv[q].y = e;
+                changed = 1;
+            } else if (pq != UNK && pp == UNK) {
+                ndv[p].x = q;
+                ndv[p].y = e;
+                changed = 1;
+            }
+        }
+        if (changed) s_flag = 1;
+        __syncthreads();
+        if (!s_flag) break;
+    }
+    {
+        int bad = 0;
+        for (int v = tid; v < V; v += ND_T)
+            if (nd[v].x == UNK) bad = 1;
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        if (bad) s_flag = 1;
+        __syncthreads();
+        if (s_flag || ntree != V - 1) {
+            if (tid == 0) sh->status = 5;
+            return;
+        }
+    }
+    if (tid == 0) {
+        for (int v = V - 1; v >= 0; --v) {
+            if (v == root) continue;
+            const int p = nd[v].x;
+            P.next_sib[v] = P.first_child[p];
+            P.first_child[p] = v;
+        }
+        int t = 1, v = root;
+        P.y[root] = 0.0;
+        nd[root].z = 0;
+        P.order[0] = root;
+        bool down = true;
+        for (long long steps = 0; steps < 4ll * V + 8; ++steps) {
+            if (down) {
+                const int c = P.first_child[v];
+                if (c >= 0) {
+                    const int a = nd[c].y;
+                    P.y[c] = (P.tail[a] == c) ? P.cost[a] + P.y[v] : P.y[v] - P.cost[a];
+                    nd[c].z = t;
+                    P.order[t] = c;
+                    ++t;
+                    v = c;
+                    continue;
+                }
+                down = false;
+            }
+            nd[v].w = t - nd[v].z;
+            if (v == root) break;
+            const int par = nd[v].x;
+            const int sb = P.next_sib[v];
+            if (sb >= 0) {
+                const int a2 = nd[sb].y;
+                P.y[sb] = (P.tail[a2] == sb) ? P.cost[a2] + P.y[par] : P.y[par] - P.cost[a2];
+                nd[sb].z = t;
+                P.order[t] = sb;
+                ++t;
+                v = sb;
+                down = true;
+            } else {
+                v = par;
+            }
+        }
+    }
+}
+
+// dual feasibility by moving arcs to their other bound; x_N for the right-hand side
+__global__ __launch_bounds__(256) void k_nd_flip(NdProblem P, double *__restrict__ xn) {
+    const long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= P.E) return;
+    int st = P.state[j];
+    double x = 0.0;
+    if (st != ST_TREE) {
+        const double rc = (P.cost[j] - P.y[P.tail[j]]) + P.y[P.head[j]];
+        const bool wrong = st == ST_LOWER ? rc < 0.0 : rc > 0.0;
+        if (wrong) {
+            if (isinf(P.cap[j])) {
+                P.sh->not_network = 1; // cannot be made dual feasible: the primal method's job
+            } else {
+                st = -st;
+                P.state[j] = static_cast<int8_t>(st);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&P.sh->flips), 1ull);
+            }
+        }
+        if (st == ST_UPPER) x = P.cap[j];
+    }
+    xn[j] = x;
+    P.flow[j] = x;
+}
+
+// e[t] = (b - A x_N)[order[t]] and the sums of its blocks of 256
+__global__ __launch_bounds__(256) void k_nd_excess(NdProblem P, const double *__restrict__ beff) {
+    __shared__ double s[256];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const double v = t < P.V ? beff[P.order[t]] : 0.0;
+    if (t < P.V) P.e[t] = v;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { // left to right: a fixed order
+        double a = 0.0;
+        for (int k = 0; k < 256; ++k) a = a + s[k];
+        P.bsum[blockIdx.x] = a;
+    }
+}
+
+// tree flows: the arc of node w carries +- the sum of e over w's preorder interval (left to right, whole
+// blocks through their sums)
+__global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= P.V) return;
+    const int4 r = P.nd[w];
+    if (r.x < 0) return;
+    int t = r.z;
+    const int end = r.z + r.w;
+    double s = 0.0;
+    while (t < end && (t & 255)) s = s + P.e[t++];
+    while (t + 256 <= end) {
+        s = s + P.bsum[t >> 8];
+        t += 256;
+    }
+    while (t < end) s = s + P.e[t++];
+    P.flow[r.y] = (P.tail[r.y] == w) ? s : -s;
+}
+
+// ------------------------------------------------------------------ workgroup reductions
+struct NdLds {
+    double d[ND_W];
+    double d2[ND_W];
+    int i[ND_W];
+    int scan[ND_W];
+    int spos[ND_PATH_LDS], ssize[ND_PATH_LDS];
+};
+
+// larger score wins, then the smaller index; result in every lane
+__device__ __forceinline__ void nd_argmax(NdLds &L, double &s, int &n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double s2 = __shfl_xor(s, o, 64);
+        const int n2 = __shfl_xor(n, o, 64);
+        if (s2 > s || (s2 == s && n2 < n)) {
+            s = s2;
+            n = n2;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        L.d[wave] = s;
+        L.i[wave] = n;
+    }
+    __syncthreads();
+    s = L.d[0];
+    n = L.i[0];
+#pragma unroll
+    for (int w = 1; w < ND_W; ++w) {
+        const double s2 = L.d[w];
+        const int n2 = L.i[w];
+        if (s2 > s || (s2 == s && n2 < n)) {
+            s = s2;
+            n = n2;
+        }
+    }
+}
+
+// smaller (r, j) wins; c travels with it; j < 0 = nothing
+__device__ __forceinline__ void nd_argmin(NdLds &L, double &r, int &j, double &c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto better = [](double r2, int j2, double r1, int j1) { return j2 >= 0 && (j1 < 0 || r2 < r1 || (r2 == r1 && j2 < j1)); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double r2 = __shfl_xor(r, o, 64), c2 = __shfl_xor(c, o, 64);
+        const int j2 = __shfl_xor(j, o, 64);
+        if (better(r2, j2, r, j)) {
+            r = r2;
+            j = j2;
+            c = c2;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        L.d[wave] = r;
+        L.d2[wave] = c;
+        L.i[wave] = j;
+    }
+    __syncthreads();
+    r = L.d[0];
+    c = L.d2[0];
+    j = L.i[0];
+#pragma unroll
+    for (int w = 1; w < ND_W; ++w)
+        if (better(L.d[w], L.i[w], r, j)) {
+            r = L.d[w];
+            c = L.d2[w];
+            j = L.i[w];
+        }
+}
+
+__device__ __forceinline__ int nd_sum(NdLds &L, int v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) L.i[wave] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < ND_W; ++w) t += L.i[w];
+    return t;
+}
+
+// ------------------------------------------------------------------ the solver
+__global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_iters, double feas_tol) {
+    cg::grid_group grid = cg::this_grid();
+    __shared__ NdLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = P.G, g = blockIdx.x;
+    const int V = P.V;
+    const long long E = P.E;
+    const long long gtid = static_cast<long long>(g) * ND_T + tid, gsize = static_cast<long long>(G) * ND_T;
+    const int gwave = g * ND_W + wave, nwaves = G * ND_W;
+    NdShared *sh = P.sh;
+    int4 *nd = P.nd;
+    const int root = sh->root;
+    long long iters = 0, flips = 0;
+    long long status = -1;
+
+    while (true) {
+        // ================================================== leaving arc
+        double bs = 0.0;
+        int bn = 0x7fffffff;
+        for (long long w = gtid; w < V; w += gsize) {
+            if (w == root) continue;
+            const int4 r = nd[w];
+            const double f = P.flow[r.y], c = P.cap[r.y];
+            const double lo = -f, hi = f - c;
+            const double viol = lo > hi ? lo : hi;
+            if (viol > feas_tol) {
+                const double s = (viol * viol) / static_cast<double>(r.w);
+                if (s > bs || (s == bs && w < bn)) {
+                    bs = s;
+                    bn = static_cast<int>(w);
+                }
+            }
+        }
+        nd_argmax(L, bs, bn);
+        if (tid == 0) {
+            P.part_s[g] = bs;
+            P.part_n[g] = bn;
+            if (g == 0) sh->cand_count = 0;
+        }
+        grid.sync(); // ---- B1
+        bs = 0.0;
+        bn = 0x7fffffff;
+        if (tid < G) {
+            bs = P.part_s[tid];
+            bn = P.part_n[tid];
+        }
+        nd_argmax(L, bs, bn);
+        if (!(bs > 0.0)) {
+            status = 0;
+            break;
+        }
+        if (iters >= max_iters) {
+            status = 3;
+            break;
+        }
+        ++iters;
+        const int v = bn;
+        const int4 rv = nd[v];
+        const int a = rv.y, a_pos = rv.z, n_sub = rv.w;
+        const double f_a = P.flow[a], cap_a = P.cap[a];
+        const bool to_lower = -f_a >= f_a - cap_a;
+        const double delta = to_lower ? -f_a : f_a - cap_a;
+        const bool a_out = P.tail[a] == v;
+        const int tau = to_lower ? (a_out ? -1 : 1) : (a_out ? 1 : -1);
+        auto in_S = [&](int p) { return p >= a_pos && p < a_pos + n_sub; };
+        // ================================================== the cut: candidates
+        auto append = [&](bool elig, int j, double r, double c) {
+            const unsigned long long m = __ballot(elig);
+            if (m == 0ull) return;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh->cand_count, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (elig) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                P.cand_j[slot] = j;
+                P.cand_r[slot] = r;
+                P.cand_c[slot] = c;
+            }
+        };
+        auto consider = [&](int j, bool tail_in, int st, bool &elig, double &r, double &c) {
+            // tail_in: the arc leaves S.  tau > 0: reduced costs of leaving arcs fall, of entering arcs rise
+            elig = tau > 0 ? (tail_in ? st == ST_LOWER : st == ST_UPPER) : (tail_in ? st == ST_UPPER : st == ST_LOWER);
+            if (elig) {
+                const double rc = (P.cost[j] - P.y[P.tail[j]]) + P.y[P.head[j]];
+                r = fabs(rc);
+                c = P.cap[j];
+            }
+        };
+        if (static_cast<long long>(n_sub) * 4 <= V) { // the adjacency of S's nodes, one wave per node
+            for (int t = a_pos + gwave; t < a_pos + n_sub; t += nwaves) {
+                const int w = P.order[t];
+                const int64_t p0 = P.rowptr[w], p1 = P.rowptr[w + 1];
+                for (int64_t p = p0; p < p1; p += 64) { // uniform trip count: the slots come from wave ballots
+                    const int64_t q = p + lane;
+                    bool elig = false;
+                    int j = -1;
+                    double r = 0.0, c = 0.0;
+                    if (q < p1) {
+                        j = P.rowarc[q];
+                        const int st = P.state[j];
+                        if (st != ST_TREE) {
+                            const int tl = P.tail[j], hd = P.head[j];
+                            const int o = tl == w ? hd : tl;
+                            if (!in_S(nd[o].z)) consider(j, tl == w, st, elig, r, c);
+                        }
+                    }
+                    append(elig, j, r, c);
+                }
+            }
+        } else { // all arcs
+            for (long long j0 = static_cast<long long>(gwave) * 64; j0 < E; j0 += static_cast<long long>(nwaves) * 64) {
+                const long long j = j0 + lane;
+                bool elig = false;
+                double r = 0.0, c = 0.0;
+                if (j < E) {
+                    const int st = P.state[j];
+                    if (st != ST_TREE) {
+                        const bool ti = in_S(nd[P.tail[j]].z), hi = in_S(nd[P.head[j]].z);
+                        if (ti != hi) consider(static_cast<int>(j), ti, st, elig, r, c);
+                    }
+                }
+                append(elig, static_cast<int>(j), r, c);
+            }
+        }
+        grid.sync(); // ---- B2
+        // ================================================== ratio test with bound flipping (workgroup 0)
+        if (g == 0) {
+            const int C = sh->cand_count;
+            double remaining = delta, last_r = -1.0;
+            int last_j = -1, npush = 0, enter = -1;
+            double theta = 0.0, cap_e = 0.0;
+            while (true) {
+                double r = 0.0, c = 0.0;
+                int j = -1;
+                for (int i = tid; i < C; i += ND_T) {
+                    const double r2 = P.cand_r[i];
+                    const int j2 = P.cand_j[i];
+                    if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
+                        r = r2;
+                        j = j2;
+                        c = P.cand_c[i];
+                    }
+                }
+                nd_argmin(L, r, j, c);
+                if (j < 0) break; // every candidate passed and the arc is still infeasible: no entering arc
+                if (c < remaining) {
+                    if (tid == 0) P.tmp[npush] = j; // tmp is free between the re-hangs
+                    ++npush;
+                    remaining = remaining - c;
+                    last_r = r;
+                    last_j = j;
+                } else {
+                    enter = j;
+                    theta = r;
+                    cap_e = c;
+                    break;
+                }
+            }
+            __syncthreads();
+            if (enter >= 0) {
+                for (int i = tid; i < npush; i += ND_T) {
+                    const int j = P.tmp[i];
+                    const int st = P.state[j];
+                    const double c = P.cap[j];
+                    P.state[j] = static_cast<int8_t>(-st);
+                    P.flow[j] = st == ST_LOWER ? c : 0.0;
+                    P.push_pt[i] = nd[P.tail[j]].z;
+                    P.push_ph[i] = nd[P.head[j]].z;
+                    P.push_d[i] = st == ST_LOWER ? c : -c;
+                }
+                if (tid == 0) {
+                    const int st = P.state[enter];
+                    const double d = st == ST_LOWER ? remaining : -remaining;
+                    const int tl = P.tail[enter], hd = P.head[enter];
+                    const int pt = nd[tl].z, ph = nd[hd].z;
+                    P.flow[enter] = (st == ST_LOWER ? 0.0 : cap_e) + d;
+                    P.state[enter] = ST_TREE;
+                    P.push_pt[npush] = pt;
+                    P.push_ph[npush] = ph;
+                    P.push_d[npush] = d;
+                    P.state[a] = static_cast<int8_t>(to_lower ? ST_LOWER : ST_UPPER);
+                    NdIter it;
+                    it.enter = enter;
+                    it.u_in = in_S(pt) ? tl : hd;
+                    it.v_in = in_S(pt) ? hd : tl;
+                    it.p_uin = in_S(pt) ? pt : ph;
+                    it.b_pos = in_S(pt) ? ph : pt;
+                    it.npush = npush + 1;
+                    it.theta = theta;
+                    sh->it = it;
+                }
+            } else if (tid == 0) {
+                sh->it.enter = -1;
+            }
+        }
+        grid.sync(); // ---- B3
+        const NdIter it = sh->it;
+        if (it.enter < 0) {
+            status = 1;
+            break;
+        }
+        flips += it.npush - 1;
+        const int enter = it.enter, u_in = it.u_in, v_in = it.v_in, p_uin = it.p_uin, b_pos = it.b_pos, npush = it.npush;
+        const double dy = tau > 0 ? it.theta : -it.theta;
+        // ================================================== flows, potentials, sizes: every node for itself
+        for (long long w = gtid; w < V; w += gsize) {
+            const int4 r = nd[w];
+            const bool inside = in_S(r.z);
+            if (w != root) {
+                double d = 0.0;
+                bool any = false;
+                for (int i = 0; i < npush; ++i) { // the subtree of w separates the ends of a moved arc
+                    const int pt = P.push_pt[i], ph = P.push_ph[i];
+                    const bool ti = pt >= r.z && pt < r.z + r.w, hi = ph >= r.z && ph < r.z + r.w;
+                    if (ti != hi) {
+                        const double x = P.push_d[i];
+                        d = d + (hi ? x : -x);
+                        any = true;
+                    }
+                }
+                if (w == v) {
+                    P.flow[a] = to_lower ? 0.0 : cap_a; // lands exactly on its bound
+                } else if (any) {
+                    P.flow[r.y] = P.flow[r.y] + ((P.tail[r.y] == w) ? d : -d);
+                }
+            }
+            if (inside) {
+                P.y[w] = P.y[w] + dy;
+            } else {
+                const bool anc_v = r.z <= a_pos && a_pos < r.z + r.w;
+                const bool anc_in = r.z <= b_pos && b_pos < r.z + r.w;
+                if (anc_v != anc_in) nd[w].w = r.w + (anc_in ? n_sub : -n_sub);
+            }
+        }
+        // the path u_in .. v inside S, in order: count my share (S is cut into G contiguous position blocks)
+        const int blk = (n_sub + G - 1) / G;
+        const int my0 = a_pos + g * blk;
+        const int my1 = (my0 + blk < a_pos + n_sub) ? my0 + blk : a_pos + n_sub;
+        {
+            int cnt = 0;
+            for (int t = my0 + tid; t < my1; t += ND_T) {
+                const int4 r = nd[P.order[t]];
+                if (r.z <= p_uin && p_uin < r.z + r.w) ++cnt;
+            }
+            cnt = nd_sum(L, cnt);
+            if (tid == 0) P.part_cnt[g] = cnt;
+        }
+        grid.sync(); // ---- B4
+        int K = 0, before = 0;
+        {
+            int c = tid < G ? P.part_cnt[tid] : 0;
+            int mine = (tid < G && tid < g) ? c : 0;
+            K = nd_sum(L, c);
+            before = nd_sum(L, mine);
+        }
+        // ordered compaction of my block: rank from the top (v first) -> index from the bottom (u_in first)
+        for (int t0 = my0; t0 < my1; t0 += ND_T) {
+            const int t = t0 + tid;
+            int4 r = make_int4(0, 0, 0, 0);
+            int w = 0;
+            bool on = false;
+            if (t < my1) {
+                w = P.order[t];
+                r = nd[w];
+                on = r.z <= p_uin && p_uin < r.z + r.w;
+            }
+            const unsigned long long m = __ballot(on);
+            __syncthreads();
+            if (lane == 0) L.scan[wave] = __popcll(m);
+            __syncthreads();
+            int wbefore = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < ND_W; ++q) {
+                wbefore += q < wave ? L.scan[q] : 0;
+                total += L.scan[q];
+            }
+            if (on) {
+                const int rank_top = before + wbefore + __popcll(m & ((1ull << lane) - 1ull));
+                const int i = K - 1 - rank_top;
+                P.snode[i] = w;
+                P.sarc[i] = r.y;
+                P.spos[i] = r.z;
+                P.ssize[i] = r.w;
+            }
+            before += total;
+        }
+        grid.sync(); // ---- B5
+        // ================================================== re-hang: S under v_in, re-rooted at u_in
+        for (long long i = gtid; i < K; i += gsize) { // every path node hangs under its former child
+            const int w = P.snode[i];
+            nd[w].x = i == 0 ? v_in : P.snode[i - 1];
+            nd[w].y = i == 0 ? enter : P.sarc[i - 1];
+            nd[w].w = i == 0 ? n_sub : n_sub - P.ssize[i - 1];
+        }
+        const int lo = a_pos < b_pos + 1 ? a_pos : b_pos + 1;
+        const int hi = a_pos + n_sub > b_pos + 1 ? a_pos + n_sub : b_pos + 1;
+        const int newstart = b_pos < a_pos ? b_pos + 1 : b_pos + 1 - n_sub;
+        const bool cached = K <= ND_PATH_LDS;
+        if (cached) {
+            __syncthreads();
+            for (int i = tid; i < K; i += ND_T) {
+                L.spos[i] = P.spos[i];
+                L.ssize[i] = P.ssize[i];
+            }
+            __syncthreads();
+        }
+        auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
+        auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
+        for (long long t = lo + gtid; t < hi; t += gsize) {
+            const int w = P.order[t];
+            int nt;
+            if (t >= a_pos && t < a_pos + n_sub) {
+                int l2 = 0, h2 = K - 1; // smallest i with t inside the old segment of path node i
+                while (l2 < h2) {
+                    const int mid = (l2 + h2) >> 1;
+                    const int q0 = s_pos(mid);
+                    if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
+                    else l2 = mid + 1;
+                }
+                const int i = l2;
+                int rel, off = 0;
+                if (i == 0) {
+                    rel = static_cast<int>(t) - s_pos(0);
+                } else {
+                    const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i - 1
+                    off = hs;
+                    rel = t < hp ? static_cast<int>(t) - s_pos(i) : (hp - s_pos(i)) + (static_cast<int>(t) - (hp + hs));
+                }
+                nt = newstart + off + rel;
+            } else {
+                nt = b_pos < a_pos ? static_cast<int>(t) + n_sub : static_cast<int>(t) - n_sub;
+            }
+            P.tmp[nt - lo] = w;
+        }
+        grid.sync(); // ---- B6
+        for (long long t = lo + gtid; t < hi; t += gsize) {
+            const int w = P.tmp[t - lo];
+            P.order[t] = w;
+            nd[w].z = static_cast<int>(t);
+        }
+        // (the next iteration's first pass reads flows, capacities and sizes only; its first barrier orders the
+        // positions written here before anything that reads them)
+        (void)u_in;
+    }
+
+    // ====================================================== results
+    grid.sync();
+    // potentials once more from the tree itself (pointer jumping): the duals handed back are the tree's own
+    for (long long w = gtid; w < V; w += gsize) {
+        const int4 r = nd[w];
+        double c = 0.0;
+        int up = static_cast<int>(w);
+        if (r.x >= 0) {
+            c = (P.tail[r.y] == w) ? P.cost[r.y] : -P.cost[r.y];
+            up = r.x;
+        }
+        P.acc[0][w] = c;
+        P.anc[0][w] = up;
+    }
+    grid.sync();
+    int cur = 0;
+    for (int round = 0; round < 32; ++round) {
+        int moved = 0;
+        for (long long w = gtid; w < V; w += gsize) {
+            const int p = P.anc[cur][w];
+            const int p2 = P.anc[cur][p];
+            P.acc[1 - cur][w] = P.acc[cur][w] + P.acc[cur][p];
+            P.anc[1 - cur][w] = p2;
+            if (p2 != p) moved = 1;
+        }
+        moved = nd_sum(L, moved);
+        if (tid == 0) P.part_cnt[g] = moved;
+        grid.sync();
+        int any = tid < G ? P.part_cnt[tid] : 0;
+        any = nd_sum(L, any);
+        cur = 1 - cur;
+        grid.sync(); // part_cnt is rewritten in the next round
+        if (!any) break;
+    }
+    for (long long w = gtid; w < V; w += gsize) P.y[w] = P.acc[cur][w];
+    // objective and largest bound violation: fixed order (lane-strided partials, workgroup order)
+    double part = 0.0, worst = 0.0;
+    for (long long e = gtid; e < E; e += gsize) {
+        const double f = P.flow[e];
+        part += P.cost[e] * f;
+        const double viol = -f > f - P.cap[e] ? -f : f - P.cap[e];
+        if (viol > worst) worst = viol;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        part += __shfl_down(part, o, 64);
+        const double w2 = __shfl_down(worst, o, 64);
+        worst = w2 > worst ? w2 : worst;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        L.d[wave] = part;
+        L.d2[wave] = worst;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0, wm = 0.0;
+        for (int w = 0; w < ND_W; ++w) {
+            tot += L.d[w];
+            wm = L.d2[w] > wm ? L.d2[w] : wm;
+        }
+        P.part_s[g] = tot;
+        P.acc[1 - cur][g] = wm; // (free again)
+    }
+    grid.sync();
+    if (g == 0 && tid == 0) {
+        double tot = 0.0, wm = 0.0;
+        for (int k = 0; k < G; ++k) {
+            tot += P.part_s[k];
+            wm = P.acc[1 - cur][k] > wm ? P.acc[1 - cur][k] : wm;
+        }
+        sh->obj = tot;
+        sh->max_violation = wm;
+        sh->iters = iters;
+        sh->flips += flips;
+        sh->status = status;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nd_outputs(int64_t V, int64_t E, const int8_t *__restrict__ state, int root,
+                                                    int8_t *__restrict__ vbasis, int8_t *__restrict__ cbasis) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (vbasis && i < E) vbasis[i] = static_cast<int8_t>(state[i] == ST_TREE ? 0 : state[i] == ST_LOWER ? -1 : -2);
+    if (cbasis && i < V) cbasis[i] = static_cast<int8_t>(i == root ? 0 : -1);
+}
+
+struct Pool { // device temporaries of one call
+    std::vector<void *> p;
+    ~Pool() {
+        for (void *q : p) (void)hipFree(q);
+    }
+    template <class T>
+    int get(size_t count, T **out) {
+        void *d = nullptr;
+        SX_HIP(hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+        p.push_back(d);
+        *out = static_cast<T *>(d);
+        return SX_OK;
+    }
+};
+
+} // namespace
+
+SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                          const double *u, const int8_t *vbasis_in, const int8_t *cbasis_in, int64_t max_iter,
+                          double feas_tol, double *x_out, double *y_out, int8_t *vbasis_out, int8_t *cbasis_out,
+                          sx_simplex_result *result) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A && b && c && l && u && vbasis_in && cbasis_in && result, "NULL argument");
+    SX_REQUIRE(A->ctx->device == ctx->device, "matrix lives on another device");
+    SX_REQUIRE(A->csc_ptr && A->csr_ptr, "matrix needs both layouts");
+    memset(result, 0, sizeof(*result));
+    result->status = 5;
+    const int64_t V = A->m, E = A->n;
+    if (V < 2 || E < 1 || V >= (static_cast<int64_t>(1) << 30) || E >= (static_cast<int64_t>(1) << 30) || A->nnz != 2 * E)
+        return SX_OK; // not a network: the caller takes another method
+    if (ctx->opt_netdual == 0) return SX_OK;
+    hipStream_t s = ctx->stream;
+    Pool pool;
+    NdProblem P;
+    memset(&P, 0, sizeof(P));
+    P.V = static_cast<int>(V);
+    P.E = E;
+    P.rowptr = A->csr_ptr;
+    P.rowarc = A->csr_idx;
+    P.cost = c;
+    P.cap = u;
+    double *xn, *beff;
+    SX_TRY(pool.get(E, &P.tail));
+    SX_TRY(pool.get(E, &P.head));
+    SX_TRY(pool.get(E, &P.state));
+    SX_TRY(pool.get(E, &xn));
+    SX_TRY(pool.get(V, &beff));
+    SX_TRY(pool.get(1, &P.sh));
+    SX_HIP(hipMemsetAsync(P.sh, 0, sizeof(NdShared), s));
+    hipLaunchKernelGGL(k_nd_endpoints, dim3(static_cast<unsigned>((E + 255) / 256)), dim3(256), 0, s, E, A->csc_ptr,
+                       A->csc_idx, A->csc_val, l, u, vbasis_in, P.tail, P.head, P.state, P.sh);
+    hipLaunchKernelGGL(k_nd_root, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, V, cbasis_in, P.sh);
+    NdShared sh;
+    SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    if (sh.not_network || sh.ntree != V - 1 || sh.nroot != 1) return SX_OK;
+    if (x_out) P.flow = x_out;
+    else SX_TRY(pool.get(E, &P.flow));
+    if (y_out) P.y = y_out;
+    else SX_TRY(pool.get(V, &P.y));
+    SX_TRY(pool.get(V, &P.nd));
+    SX_TRY(pool.get(V, &P.order));
+    SX_TRY(pool.get(V > E ? V : E, &P.tmp)); // preorder move (V) and passed arcs of the ratio test (E)
+    SX_TRY(pool.get(V, &P.first_child));
+    SX_TRY(pool.get(V, &P.next_sib));
+    SX_TRY(pool.get(V, &P.e));
+    SX_TRY(pool.get((V + 255) / 256, &P.bsum));
+    SX_TRY(pool.get(ND_GMAX, &P.part_s));
+    SX_TRY(pool.get(ND_GMAX, &P.part_n));
+    SX_TRY(pool.get(ND_GMAX, &P.part_cnt));
+    SX_TRY(pool.get(E, &P.cand_j));
+    SX_TRY(pool.get(E, &P.cand_r));
+    SX_TRY(pool.get(E, &P.cand_c));
+    SX_TRY(pool.get(E + 1, &P.push_pt));
+    SX_TRY(pool.get(E + 1, &P.push_ph));
+    SX_TRY(pool.get(E + 1, &P.push_d));
+    SX_TRY(pool.get(V, &P.snode));
+    SX_TRY(pool.get(V, &P.sarc));
+    SX_TRY(pool.get(V, &P.spos));
+    SX_TRY(pool.get(V, &P.ssize));
+    for (int k = 0; k < 2; ++k) {
+        SX_TRY(pool.get(V > ND_GMAX ? V : ND_GMAX, &P.acc[k]));
+        SX_TRY(pool.get(V, &P.anc[k]));
+    }
+    // ---- set-up: tree, potentials, dual feasibility by flips, tree flows
+    hipLaunchKernelGGL(k_nd_tree, dim3(1), dim3(ND_T), 0, s, P);
+    hipLaunchKernelGGL(k_nd_flip, dim3(static_cast<unsigned>((E + 255) / 256)), dim3(256), 0, s, P, xn);
+    SX_HIP(hipGetLastError());
+    SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    if (sh.status == 5 || sh.not_network) return SX_OK; // not a tree / an uncapacitated arc would have to flip
+    SX_TRY(sx_score_rows_dev(ctx, A, xn, b, nullptr, 0.0, beff, nullptr)); // b - A x_N, sums in stored order
+    hipLaunchKernelGGL(k_nd_excess, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, beff);
+    hipLaunchKernelGGL(k_nd_initflows, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P);
+    // ---- the cooperative grid: as many workgroups as the passes can use, all resident
+    int per_cu = 0;
+    SX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_nd_solve, ND_T, 0));
+    int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    int64_t want = ((V > E / 8 ? V : E / 8) + ND_T - 1) / ND_T;
+    int G = static_cast<int>(want < 1 ? 1 : want);
+    if (ctx->opt_nd_grid > 0) G = ctx->opt_nd_grid;
+    if (G > ND_GMAX) G = ND_GMAX;
+    if (G > per_cu * cus) G = per_cu * cus;
+    if (G < 1) G = 1;
+    P.G = G;
+    long long limit = max_iter > 0 ? max_iter : 100 * (V + E);
+    void *args[] = {&P, &limit, &feas_tol};
+    SX_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_nd_solve), dim3(static_cast<unsigned>(G)), dim3(ND_T),
+                                      args, 0, s));
+    hipLaunchKernelGGL(k_nd_outputs, dim3(static_cast<unsigned>(((E > V ? E : V) + 255) / 256)), dim3(256), 0, s, V, E,
+                       P.state, sh.root, vbasis_out, cbasis_out);
+    SX_HIP(hipGetLastError());
+    SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    if (getenv("SX_NS_PROFILE"))
+        fprintf(stderr, "[sx_netdual] V=%lld E=%lld grid=%d iterations=%lld flips=%lld status=%lld\n", (long long)V, (long long)E,
+                G, sh.iters, sh.flips, sh.status);
+    result->status = sh.status;
+    result->iters = sh.iters;
+    result->phase1_iters = sh.flips; // arcs moved bound to bound (at the start and by the ratio test)
+    result->warm_start_used = 1;
+    result->obj = sh.obj;
+    result->max_violation = sh.max_violation;
+    return SX_OK;
+}

@@ -12,7 +12,10 @@
 
 #include "sx_segwalk.h"
 
-constexpr int SXL_CAP = 4096;   // window length in doubles (32 KiB of LDS)
+#ifndef SXL_CAP_V
+#define SXL_CAP_V 4096
+#endif
+constexpr int SXL_CAP = SXL_CAP_V;   // window length in doubles (32 KiB of LDS)
 constexpr int SXL_CHUNK = 1024; // staged entries per chunk of the windowed walk: 8 KiB of LDS, so that window + chunk
                                 // = 40 KiB and FOUR workgroups share a CU (2048: three; K1 0.341 -> 0.312 ms at c5)
 

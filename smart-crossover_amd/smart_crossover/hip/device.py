@@ -273,6 +273,16 @@ class Context:
                                              _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
 
+    def net_dual(self, A, b, c, l, u, vbasis, cbasis, max_iter=0, feas_tol=1e-9, x=None, y=None, vbasis_out=None,
+                 cbasis_out=None) -> "_l.SimplexResult":
+        """K16d (blocking): dual network simplex from a spanning-tree basis that need not be primal feasible;
+        status 5 = outside its domain (the caller then takes ``net_simplex`` / ``simplex``)."""
+        res = _l.SimplexResult()
+        _l.check(self._lib.sx_netdual_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(vbasis),
+                                          _ptr(cbasis), int(max_iter), float(feas_tol), _ptr(x), _ptr(y),
+                                          _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+        return res
+
     def simplex_session(self) -> "SimplexSession":
         return SimplexSession(self)
 

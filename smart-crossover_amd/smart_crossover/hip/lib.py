@@ -125,6 +125,8 @@ PROTOTYPES = {
                                         C.POINTER(SimplexResult)]),
     "sx_netsimplex_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  C.POINTER(SimplexResult)]),
+    "sx_netdual_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp,
+                              C.POINTER(SimplexResult)]),
     "sx_sinkhorn_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,
                                C.POINTER(SinkhornResult)]),
     "sx_sinkhorn_batch_dev": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _dbl, _i64, _dbl, _vp, _vp, _vp,

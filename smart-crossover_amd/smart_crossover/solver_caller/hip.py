@@ -35,6 +35,7 @@ from smart_crossover.solver_caller.caller import SolverCaller, SolverSettings
 _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
 
+NETDUAL_FEAS_TOL = 1e-9  # bound violation of a tree arc the dual network simplex still calls feasible
 CRASH_MARGIN = 1e-6      # a column this far (relative) inside its bounds / a slack this large counts as basic
 
 
@@ -179,14 +180,20 @@ class HipCaller(SolverCaller):
         t0 = time.perf_counter()
         d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
         self._res = None
+        self.solved_by = "simplex"
         if self._network and vb_in is not None and x_start is None and not self._row_lt.any():
-            # a network sub-problem with a warm tree basis: network simplex on the tree (K16n); status 5 = the
-            # basis is not a primal feasible spanning tree (or A is no incidence matrix): general simplex below
-            res = ctx.net_simplex(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol),
-                                  d_x, d_y, d_vb, d_cb)
+            # a network sub-problem with a warm tree basis.  First the dual method on the whole GPU (K16d: the
+            # tree need not be primal feasible, new arcs at the wrong bound are flipped); status 5 = outside its
+            # domain (an uncapacitated arc would have to flip, A is no incidence matrix, not a tree).  Then the
+            # primal network simplex (K16n: needs a primal feasible tree); status 5 again: general simplex below
+            res = ctx.net_dual(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, NETDUAL_FEAS_TOL, d_x, d_y, d_vb, d_cb)
             if int(res.status) != 5:
-                self._res = res
-        self.solved_by = "netsimplex" if self._res is not None else "simplex"
+                self._res, self.solved_by = res, "netdual"
+            else:
+                res = ctx.net_simplex(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol),
+                                      d_x, d_y, d_vb, d_cb)
+                if int(res.status) != 5:
+                    self._res, self.solved_by = res, "netsimplex"
         if self._res is None:
             self._res = ctx.simplex(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt),
                                     vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb,

@@ -157,10 +157,11 @@ def test_unbounded_is_detected(ctx):
     assert int(run(ctx, A, b, c, u, vb, cb)[0].status) == 2
 
 
-@pytest.mark.parametrize("V,E", [(512, 4096), (4096, 32768)])
-def test_cnet_mcf_runs_on_the_network_simplex_and_agrees_with_highs(ctx, V, E, capsys):
+@pytest.mark.parametrize("V,E,netdual", [(512, 4096, -1), (512, 4096, 0), (4096, 32768, -1), (4096, 32768, 0)])
+def test_cnet_mcf_runs_on_the_network_simplex_and_agrees_with_highs(ctx, V, E, netdual, capsys):
     """The whole CNET_MCF crossover with solver='HIP': every round's re-solve is a network LP with a warm tree
-    basis (round 0: the artificial star) -> K16n.  Same optimal cost as the HiGHS-backed run."""
+    basis (round 0: the artificial star) -> the dual network simplex K16d, or with "netdual" 0 the primal one
+    K16n.  Same optimal cost as the HiGHS-backed run."""
     from smart_crossover.formats import MinCostFlow
     from smart_crossover.network_methods.algorithms import network_crossover
     from smart_crossover.solver_caller import hip as hipmod
@@ -173,6 +174,7 @@ def test_cnet_mcf_runs_on_the_network_simplex_and_agrees_with_highs(ctx, V, E, c
         used.append(self.solved_by)
 
     hipmod.HipCaller._solve = spy
+    ctx.set_option("netdual", netdual)
     try:
         for solver in ("HIP", "HGS"):
             inst = workloads.mcf(V, E, 3)
@@ -181,6 +183,7 @@ def test_cnet_mcf_runs_on_the_network_simplex_and_agrees_with_highs(ctx, V, E, c
             costs[solver] = float(inst.c @ out.x[:E]) if out.x.size >= E else float(out.obj_val)
     finally:
         hipmod.HipCaller._solve = orig
+        ctx.set_option("netdual", -1)
     capsys.readouterr()
-    assert used and all(how == "netsimplex" for how in used)
+    assert used and all(how == ("netsimplex" if netdual == 0 else "netdual") for how in used)
     assert costs["HIP"] == pytest.approx(costs["HGS"], rel=1e-9)
