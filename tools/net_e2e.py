@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--ns-block", type=int, default=0, help="ctx option ns_block (arcs priced per lane and block; 0 = by size)")
     ap.add_argument("--ns-lds", type=int, default=1)
     ap.add_argument("--netsimplex", type=int, default=-1)
+    ap.add_argument("--netdual", type=int, default=-1, help="ctx option netdual (0: primal network simplex only)")
+    ap.add_argument("--nd-grid", type=int, default=0, help="ctx option nd_grid (workgroups of the dual method's grid)")
     ap.add_argument("--c3", action="store_true", help="also time bench.py's network leg (TNET on config 3)")
     args = ap.parse_args()
     if "HIP" in args.solvers:
@@ -46,6 +48,8 @@ def main():
         default_context().set_option("ns_block", args.ns_block)
         default_context().set_option("ns_lds", args.ns_lds)
         default_context().set_option("netsimplex", args.netsimplex)
+        default_context().set_option("netdual", args.netdual)
+        default_context().set_option("nd_grid", args.nd_grid)
     if args.c3:
         import bench
         rec = bench.crossover_network()
@@ -84,7 +88,7 @@ def main():
                 finally:
                     cls.return_output = orig
                 wall = time.perf_counter() - t0
-                rec = {"case": f"cnet_mcf V={V} E={E}", "solver": solver, "ns_block": args.ns_block, "ns_lds": args.ns_lds, "netsimplex": args.netsimplex, "run": rep, "wall_ms": wall * 1e3,
+                rec = {"case": f"cnet_mcf V={V} E={E}", "solver": solver, "ns_block": args.ns_block, "ns_lds": args.ns_lds, "netsimplex": args.netsimplex, "netdual": args.netdual, "nd_grid": args.nd_grid, "run": rep, "wall_ms": wall * 1e3,
                        "solver_ms": sum(s["ms"] for s in solves), "simplex_iterations": int(out.iter_count),
                        "solves": solves, "cost": float(inst.c @ out.x[:E])}
                 print(json.dumps(rec), flush=True)
