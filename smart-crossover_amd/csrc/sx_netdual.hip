@@ -37,17 +37,22 @@ namespace {
 constexpr int ND_T = 1024;       // lanes per workgroup
 constexpr int ND_W = ND_T / 64;  // waves per workgroup
 constexpr int ND_GMAX = 256;     // workgroups of the cooperative grid (one per CU at most)
-constexpr int ND_PATH_LDS = 2048; // path entries cached in LDS for the preorder move
+constexpr int ND_PATH_LDS = 2048; // path entries cached in LDS for the new positions
+constexpr int ND_SMALL = 2048;    // subtrees up to this many nodes: workgroup 0 scans the cut alone
 constexpr int ST_TREE = 0, ST_LOWER = 1, ST_UPPER = -1;
 constexpr int UNK = -2;
 
-struct NdIter { // the iteration's decisions: written by workgroup 0, read by all
+struct NdDec { // an iteration's decision: written by workgroup 0, applied by all in the next pass
+    int has;        // 0 before the first iteration
     int enter;      // entering arc, -1: none (primal infeasible)
-    int u_in, v_in; // its end inside / outside the subtree
-    int p_uin;      // pos[u_in]
+    int v_in;       // its end outside the subtree S
     int b_pos;      // pos[v_in]
-    int npush;      // moved arcs: the passed ones and, last, the entering arc
-    double theta;   // |reduced cost| of the entering arc
+    int a_pos, n_sub; // S = old positions [a_pos, a_pos + n_sub)
+    int K;          // nodes on the path u_in .. v (snode / sarc / spos / ssize, u_in first)
+    int npush;      // moved arcs: the passed ones and, last, the entering arc (push_pt / push_ph / push_d)
+    int to_lower;   // the leaving arc lands on 0 (else on its capacity)
+    int lo, hi, newstart; // preorder positions [lo, hi) change; S starts at newstart
+    double dy;      // shift of the potentials of S
 };
 
 struct NdShared {
@@ -60,7 +65,10 @@ struct NdShared {
     int ntree, nroot, root;
     int cand_count;
     int pad_;
-    NdIter it;
+    NdDec dec;
+    // SX_NS_PROFILE: 10 ns ticks per phase (workgroup 0) and sums over the iterations
+    long long t_phase[8];
+    long long sum_cand, sum_sub, sum_path, sum_range, n_small;
 };
 
 struct NdProblem {
@@ -87,6 +95,7 @@ struct NdProblem {
     int32_t *push_pt, *push_ph;
     double *push_d;
     int32_t *snode, *sarc, *spos, *ssize;
+    int32_t *pathidx; // [V] 1 + index on the path of the pending decision, 0 elsewhere
     double *acc[2];
     int32_t *anc[2];
     NdShared *sh;
@@ -307,6 +316,7 @@ struct NdLds {
     int i[ND_W];
     int scan[ND_W];
     int spos[ND_PATH_LDS], ssize[ND_PATH_LDS];
+    int s_node[ND_SMALL], s_p0[ND_SMALL], s_off[ND_SMALL]; // workgroup 0: the nodes of a small S and their rows
 };
 
 // larger score wins, then the smaller index; result in every lane
@@ -387,6 +397,17 @@ __device__ __forceinline__ int nd_sum(NdLds &L, int v) {
 }
 
 // ------------------------------------------------------------------ the solver
+// Two grid barriers per iteration:
+//   pass   every node for itself, all workgroups: the previous iteration's decision is applied IN PLACE -- flow of
+//          the node's tree arc (the subtree separates the ends of a moved arc), potential (inside S), subtree size
+//          (ancestors of the two attachment points), the re-rooted path nodes' parent / arc / size, the node's
+//          new preorder position and its slot of order[] -- nobody reads another node's data in this pass, so no
+//          temporary copy and no barrier in between; then the node's violation^2 / size, two-level argmax
+//   ----   barrier
+//   decide workgroup 0 (the others wait): the cut from the adjacency of S's nodes, ratio test with bound
+//          flipping, the path u_in .. v in order; publishes the decision.  A subtree of more than ND_SMALL nodes
+//          (1 % of the iterations) has its cut scanned by all workgroups first, one more barrier
+//   ----   barrier
 __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_iters, double feas_tol) {
     cg::grid_group grid = cg::this_grid();
     __shared__ NdLds L;
@@ -401,22 +422,121 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
     const int root = sh->root;
     long long iters = 0, flips = 0;
     long long status = -1;
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum_cand = 0, sum_sub = 0, sum_path = 0, sum_range = 0, n_small = 0;
+    long long tc = wall_clock64();
+    auto tick = [&](int k) {
+        const long long now = wall_clock64();
+        tph[k] += now - tc;
+        tc = now;
+    };
+    int prev_K = 0; // workgroup 0: path marks to clear
 
     while (true) {
-        // ================================================== leaving arc
+        // ================================================== pass: apply the decision, score the tree arcs
+        const NdDec D = sh->dec;
+        if (D.has && D.enter < 0) {
+            status = 1;
+            break;
+        }
+        const bool cached = D.has && D.K <= ND_PATH_LDS;
+        if (cached) {
+            __syncthreads();
+            for (int i = tid; i < D.K; i += ND_T) {
+                L.spos[i] = P.spos[i];
+                L.ssize[i] = P.ssize[i];
+            }
+            __syncthreads();
+        }
+        auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
+        auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
         double bs = 0.0;
         int bn = 0x7fffffff;
         for (long long w = gtid; w < V; w += gsize) {
-            if (w == root) continue;
-            const int4 r = nd[w];
-            const double f = P.flow[r.y], c = P.cap[r.y];
-            const double lo = -f, hi = f - c;
-            const double viol = lo > hi ? lo : hi;
-            if (viol > feas_tol) {
-                const double s = (viol * viol) / static_cast<double>(r.w);
-                if (s > bs || (s == bs && w < bn)) {
-                    bs = s;
-                    bn = static_cast<int>(w);
+            int4 r = nd[w];
+            if (D.has) {
+                const bool inside = r.z >= D.a_pos && r.z < D.a_pos + D.n_sub;
+                const int pi = inside ? P.pathidx[w] : 0; // 1 + index on the path u_in .. v
+                if (w != root) {
+                    // the arc that hangs w after the re-hang, and the subtree it closed before: a path node takes
+                    // over the arc of the path node below it
+                    int arc = r.y, iz = r.z, iw = r.w, owner = static_cast<int>(w);
+                    if (pi > 0) {
+                        if (pi == D.K) P.flow[r.y] = D.to_lower ? 0.0 : P.cap[r.y]; // the leaving arc lands on its bound
+                        if (pi == 1) {
+                            arc = -1; // the entering arc: workgroup 0 set its flow
+                        } else {
+                            arc = P.sarc[pi - 2];
+                            iz = s_pos(pi - 2);
+                            iw = s_size(pi - 2);
+                            owner = P.snode[pi - 2];
+                        }
+                    }
+                    if (arc >= 0) {
+                        double d = 0.0;
+                        bool any = false;
+                        for (int i = 0; i < D.npush; ++i) { // the subtree separates the ends of a moved arc
+                            const int pt = P.push_pt[i], ph = P.push_ph[i];
+                            const bool ti = pt >= iz && pt < iz + iw, hi = ph >= iz && ph < iz + iw;
+                            if (ti != hi) {
+                                const double x = P.push_d[i];
+                                d = d + (hi ? x : -x);
+                                any = true;
+                            }
+                        }
+                        if (any) P.flow[arc] = P.flow[arc] + ((P.tail[arc] == owner) ? d : -d);
+                    }
+                }
+                int4 q = r;
+                if (pi > 0) {
+                    q.x = pi == 1 ? D.v_in : P.snode[pi - 2];
+                    q.y = pi == 1 ? D.enter : P.sarc[pi - 2];
+                    q.w = pi == 1 ? D.n_sub : D.n_sub - s_size(pi - 2);
+                } else if (!inside) {
+                    const bool anc_v = r.z <= D.a_pos && D.a_pos < r.z + r.w;
+                    const bool anc_in = r.z <= D.b_pos && D.b_pos < r.z + r.w;
+                    if (anc_v != anc_in) q.w = r.w + (anc_in ? D.n_sub : -D.n_sub);
+                }
+                if (inside) P.y[w] = P.y[w] + D.dy;
+                if (r.z >= D.lo && r.z < D.hi) { // S moves right behind v_in, re-rooted at u_in
+                    const int t = r.z;
+                    int nt;
+                    if (inside) {
+                        int l2 = 0, h2 = D.K - 1; // smallest i with t inside the old segment of path node i
+                        while (l2 < h2) {
+                            const int mid = (l2 + h2) >> 1;
+                            const int q0 = s_pos(mid);
+                            if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
+                            else l2 = mid + 1;
+                        }
+                        const int i = l2;
+                        int rel, off = 0;
+                        if (i == 0) {
+                            rel = t - s_pos(0);
+                        } else {
+                            const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i - 1
+                            off = hs;
+                            rel = t < hp ? t - s_pos(i) : (hp - s_pos(i)) + (t - (hp + hs));
+                        }
+                        nt = D.newstart + off + rel;
+                    } else {
+                        nt = D.b_pos < D.a_pos ? t + D.n_sub : t - D.n_sub;
+                    }
+                    q.z = nt;
+                    P.order[nt] = static_cast<int>(w);
+                }
+                nd[w] = q;
+                r = q;
+            }
+            if (w != root) {
+                const double f = P.flow[r.y], c = P.cap[r.y];
+                const double lo = -f, hi = f - c;
+                const double viol = lo > hi ? lo : hi;
+                if (viol > feas_tol) {
+                    const double s = (viol * viol) / static_cast<double>(r.w);
+                    if (s > bs || (s == bs && w < bn)) {
+                        bs = s;
+                        bn = static_cast<int>(w);
+                    }
                 }
             }
         }
@@ -426,7 +546,9 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             P.part_n[g] = bn;
             if (g == 0) sh->cand_count = 0;
         }
+        tick(0);
         grid.sync(); // ---- B1
+        tick(6);
         bs = 0.0;
         bn = 0x7fffffff;
         if (tid < G) {
@@ -452,6 +574,9 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         const bool a_out = P.tail[a] == v;
         const int tau = to_lower ? (a_out ? -1 : 1) : (a_out ? 1 : -1);
         auto in_S = [&](int p) { return p >= a_pos && p < a_pos + n_sub; };
+        const bool small = n_sub <= ND_SMALL;
+        sum_sub += n_sub;
+        n_small += small ? 1 : 0;
         // ================================================== the cut: candidates
         auto append = [&](bool elig, int j, double r, double c) {
             const unsigned long long m = __ballot(elig);
@@ -475,17 +600,101 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 c = P.cap[j];
             }
         };
-        if (static_cast<long long>(n_sub) * 4 <= V) { // the adjacency of S's nodes, one wave per node
-            for (int t = a_pos + gwave; t < a_pos + n_sub; t += nwaves) {
-                const int w = P.order[t];
-                const int64_t p0 = P.rowptr[w], p1 = P.rowptr[w + 1];
-                for (int64_t p = p0; p < p1; p += 64) { // uniform trip count: the slots come from wave ballots
-                    const int64_t q = p + lane;
+        if (!small) { // a large subtree: all workgroups scan
+            if (static_cast<long long>(n_sub) * 4 <= V) { // the adjacency of S's nodes, one wave per node
+                for (int t = a_pos + gwave; t < a_pos + n_sub; t += nwaves) {
+                    const int w = P.order[t];
+                    const int64_t p0 = P.rowptr[w], p1 = P.rowptr[w + 1];
+                    for (int64_t p = p0; p < p1; p += 64) { // uniform trip count: the slots come from wave ballots
+                        const int64_t q = p + lane;
+                        bool elig = false;
+                        int j = -1;
+                        double r = 0.0, c = 0.0;
+                        if (q < p1) {
+                            j = P.rowarc[q];
+                            const int st = P.state[j];
+                            if (st != ST_TREE) {
+                                const int tl = P.tail[j], hd = P.head[j];
+                                const int o = tl == w ? hd : tl;
+                                if (!in_S(nd[o].z)) consider(j, tl == w, st, elig, r, c);
+                            }
+                        }
+                        append(elig, j, r, c);
+                    }
+                }
+            } else { // all arcs
+                for (long long j0 = static_cast<long long>(gwave) * 64; j0 < E; j0 += static_cast<long long>(nwaves) * 64) {
+                    const long long j = j0 + lane;
+                    bool elig = false;
+                    double r = 0.0, c = 0.0;
+                    if (j < E) {
+                        const int st = P.state[j];
+                        if (st != ST_TREE) {
+                            const bool ti = in_S(nd[P.tail[j]].z), hi = in_S(nd[P.head[j]].z);
+                            if (ti != hi) consider(static_cast<int>(j), ti, st, elig, r, c);
+                        }
+                    }
+                    append(elig, static_cast<int>(j), r, c);
+                }
+            }
+            tick(1);
+            grid.sync(); // ---- B2 (large subtrees only)
+            tick(6);
+        }
+        // ================================================== workgroup 0 decides
+        if (g == 0) {
+            // marks of the previous path
+            for (int i = tid; i < prev_K; i += ND_T) P.pathidx[P.snode[i]] = 0;
+            if (small) {
+                // the entries of the rows of S's nodes, flattened over the lanes: node t of S owns the entries
+                // [off[t], off[t + 1]) of the flattened list
+                int run = 0;
+                for (int t0 = 0; t0 < n_sub; t0 += ND_T) {
+                    const int t = t0 + tid;
+                    int w = -1, p0 = 0, deg = 0;
+                    if (t < n_sub) {
+                        w = P.order[a_pos + t];
+                        p0 = static_cast<int>(P.rowptr[w]);
+                        deg = static_cast<int>(P.rowptr[w + 1]) - p0;
+                    }
+                    int incl = deg;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int up = __shfl_up(incl, o, 64);
+                        if (lane >= o) incl += up;
+                    }
+                    __syncthreads();
+                    if (lane == 63) L.scan[wave] = incl;
+                    __syncthreads();
+                    int before = run, total = 0;
+#pragma unroll
+                    for (int q = 0; q < ND_W; ++q) {
+                        before += q < wave ? L.scan[q] : 0;
+                        total += L.scan[q];
+                    }
+                    if (t < n_sub) {
+                        L.s_node[t] = w;
+                        L.s_p0[t] = p0;
+                        L.s_off[t] = before + incl - deg;
+                    }
+                    run += total;
+                }
+                __syncthreads();
+                const int T = run;
+                for (int e0 = 0; e0 < T; e0 += ND_T) { // uniform trip count: the slots come from wave ballots
+                    const int e = e0 + tid;
                     bool elig = false;
                     int j = -1;
                     double r = 0.0, c = 0.0;
-                    if (q < p1) {
-                        j = P.rowarc[q];
+                    if (e < T) {
+                        int l2 = 0, h2 = n_sub - 1; // largest t with off[t] <= e
+                        while (l2 < h2) {
+                            const int mid = (l2 + h2 + 1) >> 1;
+                            if (L.s_off[mid] <= e) l2 = mid;
+                            else h2 = mid - 1;
+                        }
+                        const int w = L.s_node[l2];
+                        j = P.rowarc[L.s_p0[l2] + (e - L.s_off[l2])];
                         const int st = P.state[j];
                         if (st != ST_TREE) {
                             const int tl = P.tail[j], hd = P.head[j];
@@ -495,33 +704,31 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     }
                     append(elig, j, r, c);
                 }
+                __syncthreads();
             }
-        } else { // all arcs
-            for (long long j0 = static_cast<long long>(gwave) * 64; j0 < E; j0 += static_cast<long long>(nwaves) * 64) {
-                const long long j = j0 + lane;
-                bool elig = false;
-                double r = 0.0, c = 0.0;
-                if (j < E) {
-                    const int st = P.state[j];
-                    if (st != ST_TREE) {
-                        const bool ti = in_S(nd[P.tail[j]].z), hi = in_S(nd[P.head[j]].z);
-                        if (ti != hi) consider(static_cast<int>(j), ti, st, elig, r, c);
-                    }
-                }
-                append(elig, static_cast<int>(j), r, c);
-            }
-        }
-        grid.sync(); // ---- B2
-        // ================================================== ratio test with bound flipping (workgroup 0)
-        if (g == 0) {
+            tick(2);
+            // ---- ratio test with bound flipping: candidates in ascending (|reduced cost|, arc)
             const int C = sh->cand_count;
+            sum_cand += C;
+            double r0 = 0.0, c0 = 0.0; // this lane's first candidate, kept in registers over the rounds
+            int j0 = -1;
+            if (tid < C) {
+                r0 = P.cand_r[tid];
+                c0 = P.cand_c[tid];
+                j0 = P.cand_j[tid];
+            }
             double remaining = delta, last_r = -1.0;
             int last_j = -1, npush = 0, enter = -1;
             double theta = 0.0, cap_e = 0.0;
             while (true) {
                 double r = 0.0, c = 0.0;
                 int j = -1;
-                for (int i = tid; i < C; i += ND_T) {
+                if (j0 >= 0 && (r0 > last_r || (r0 == last_r && j0 > last_j))) {
+                    r = r0;
+                    c = c0;
+                    j = j0;
+                }
+                for (int i = tid + ND_T; i < C; i += ND_T) {
                     const double r2 = P.cand_r[i];
                     const int j2 = P.cand_j[i];
                     if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
@@ -533,7 +740,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 nd_argmin(L, r, j, c);
                 if (j < 0) break; // every candidate passed and the arc is still infeasible: no entering arc
                 if (c < remaining) {
-                    if (tid == 0) P.tmp[npush] = j; // tmp is free between the re-hangs
+                    if (tid == 0) P.tmp[npush] = j;
                     ++npush;
                     remaining = remaining - c;
                     last_r = r;
@@ -546,7 +753,61 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 }
             }
             __syncthreads();
+            tick(3);
+            NdDec N;
+            memset(&N, 0, sizeof(N));
+            N.has = 1;
+            N.enter = enter;
             if (enter >= 0) {
+                const int tl = P.tail[enter], hd = P.head[enter];
+                const int pt = nd[tl].z, ph = nd[hd].z;
+                const bool t_in = in_S(pt);
+                const int u_in = t_in ? tl : hd, p_uin = t_in ? pt : ph, b_pos = t_in ? ph : pt;
+                // ---- the path u_in .. v inside S in order: ancestors of u_in, by position (= from v downwards)
+                int K = 0;
+                for (int t0 = 0; t0 < n_sub; t0 += ND_T) {
+                    const int t = t0 + tid;
+                    bool on = false;
+                    if (t < n_sub) {
+                        const int w = small ? L.s_node[t] : P.order[a_pos + t];
+                        const int4 r = nd[w];
+                        on = r.z <= p_uin && p_uin < r.z + r.w;
+                    }
+                    K += on ? 1 : 0;
+                }
+                K = nd_sum(L, K);
+                int before = 0;
+                for (int t0 = 0; t0 < n_sub; t0 += ND_T) {
+                    const int t = t0 + tid;
+                    bool on = false;
+                    int w = 0;
+                    int4 r = make_int4(0, 0, 0, 0);
+                    if (t < n_sub) {
+                        w = small ? L.s_node[t] : P.order[a_pos + t];
+                        r = nd[w];
+                        on = r.z <= p_uin && p_uin < r.z + r.w;
+                    }
+                    const unsigned long long m = __ballot(on);
+                    __syncthreads();
+                    if (lane == 0) L.scan[wave] = __popcll(m);
+                    __syncthreads();
+                    int wbefore = 0, total = 0;
+#pragma unroll
+                    for (int q = 0; q < ND_W; ++q) {
+                        wbefore += q < wave ? L.scan[q] : 0;
+                        total += L.scan[q];
+                    }
+                    if (on) {
+                        const int i = K - 1 - (before + wbefore + __popcll(m & ((1ull << lane) - 1ull)));
+                        P.snode[i] = w;
+                        P.sarc[i] = r.y;
+                        P.spos[i] = r.z;
+                        P.ssize[i] = r.w;
+                        P.pathidx[w] = i + 1;
+                    }
+                    before += total;
+                }
+                // ---- moved arcs: the passed ones change bound, the entering arc takes what is left
                 for (int i = tid; i < npush; i += ND_T) {
                     const int j = P.tmp[i];
                     const int st = P.state[j];
@@ -560,176 +821,35 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 if (tid == 0) {
                     const int st = P.state[enter];
                     const double d = st == ST_LOWER ? remaining : -remaining;
-                    const int tl = P.tail[enter], hd = P.head[enter];
-                    const int pt = nd[tl].z, ph = nd[hd].z;
                     P.flow[enter] = (st == ST_LOWER ? 0.0 : cap_e) + d;
                     P.state[enter] = ST_TREE;
                     P.push_pt[npush] = pt;
                     P.push_ph[npush] = ph;
                     P.push_d[npush] = d;
                     P.state[a] = static_cast<int8_t>(to_lower ? ST_LOWER : ST_UPPER);
-                    NdIter it;
-                    it.enter = enter;
-                    it.u_in = in_S(pt) ? tl : hd;
-                    it.v_in = in_S(pt) ? hd : tl;
-                    it.p_uin = in_S(pt) ? pt : ph;
-                    it.b_pos = in_S(pt) ? ph : pt;
-                    it.npush = npush + 1;
-                    it.theta = theta;
-                    sh->it = it;
                 }
-            } else if (tid == 0) {
-                sh->it.enter = -1;
+                N.v_in = t_in ? hd : tl;
+                N.b_pos = b_pos;
+                N.npush = npush + 1;
+                N.K = K;
+                N.a_pos = a_pos;
+                N.n_sub = n_sub;
+                N.to_lower = to_lower ? 1 : 0;
+                N.dy = tau > 0 ? theta : -theta;
+                N.lo = a_pos < b_pos + 1 ? a_pos : b_pos + 1;
+                N.hi = a_pos + n_sub > b_pos + 1 ? a_pos + n_sub : b_pos + 1;
+                N.newstart = b_pos < a_pos ? b_pos + 1 : b_pos + 1 - n_sub;
+                prev_K = K;
+                flips += npush;
+                sum_path += K;
+                sum_range += N.hi - N.lo;
+                (void)u_in;
             }
+            if (tid == 0) sh->dec = N;
+            tick(4);
         }
         grid.sync(); // ---- B3
-        const NdIter it = sh->it;
-        if (it.enter < 0) {
-            status = 1;
-            break;
-        }
-        flips += it.npush - 1;
-        const int enter = it.enter, u_in = it.u_in, v_in = it.v_in, p_uin = it.p_uin, b_pos = it.b_pos, npush = it.npush;
-        const double dy = tau > 0 ? it.theta : -it.theta;
-        // ================================================== flows, potentials, sizes: every node for itself
-        for (long long w = gtid; w < V; w += gsize) {
-            const int4 r = nd[w];
-            const bool inside = in_S(r.z);
-            if (w != root) {
-                double d = 0.0;
-                bool any = false;
-                for (int i = 0; i < npush; ++i) { // the subtree of w separates the ends of a moved arc
-                    const int pt = P.push_pt[i], ph = P.push_ph[i];
-                    const bool ti = pt >= r.z && pt < r.z + r.w, hi = ph >= r.z && ph < r.z + r.w;
-                    if (ti != hi) {
-                        const double x = P.push_d[i];
-                        d = d + (hi ? x : -x);
-                        any = true;
-                    }
-                }
-                if (w == v) {
-                    P.flow[a] = to_lower ? 0.0 : cap_a; // lands exactly on its bound
-                } else if (any) {
-                    P.flow[r.y] = P.flow[r.y] + ((P.tail[r.y] == w) ? d : -d);
-                }
-            }
-            if (inside) {
-                P.y[w] = P.y[w] + dy;
-            } else {
-                const bool anc_v = r.z <= a_pos && a_pos < r.z + r.w;
-                const bool anc_in = r.z <= b_pos && b_pos < r.z + r.w;
-                if (anc_v != anc_in) nd[w].w = r.w + (anc_in ? n_sub : -n_sub);
-            }
-        }
-        // the path u_in .. v inside S, in order: count my share (S is cut into G contiguous position blocks)
-        const int blk = (n_sub + G - 1) / G;
-        const int my0 = a_pos + g * blk;
-        const int my1 = (my0 + blk < a_pos + n_sub) ? my0 + blk : a_pos + n_sub;
-        {
-            int cnt = 0;
-            for (int t = my0 + tid; t < my1; t += ND_T) {
-                const int4 r = nd[P.order[t]];
-                if (r.z <= p_uin && p_uin < r.z + r.w) ++cnt;
-            }
-            cnt = nd_sum(L, cnt);
-            if (tid == 0) P.part_cnt[g] = cnt;
-        }
-        grid.sync(); // ---- B4
-        int K = 0, before = 0;
-        {
-            int c = tid < G ? P.part_cnt[tid] : 0;
-            int mine = (tid < G && tid < g) ? c : 0;
-            K = nd_sum(L, c);
-            before = nd_sum(L, mine);
-        }
-        // ordered compaction of my block: rank from the top (v first) -> index from the bottom (u_in first)
-        for (int t0 = my0; t0 < my1; t0 += ND_T) {
-            const int t = t0 + tid;
-            int4 r = make_int4(0, 0, 0, 0);
-            int w = 0;
-            bool on = false;
-            if (t < my1) {
-                w = P.order[t];
-                r = nd[w];
-                on = r.z <= p_uin && p_uin < r.z + r.w;
-            }
-            const unsigned long long m = __ballot(on);
-            __syncthreads();
-            if (lane == 0) L.scan[wave] = __popcll(m);
-            __syncthreads();
-            int wbefore = 0, total = 0;
-#pragma unroll
-            for (int q = 0; q < ND_W; ++q) {
-                wbefore += q < wave ? L.scan[q] : 0;
-                total += L.scan[q];
-            }
-            if (on) {
-                const int rank_top = before + wbefore + __popcll(m & ((1ull << lane) - 1ull));
-                const int i = K - 1 - rank_top;
-                P.snode[i] = w;
-                P.sarc[i] = r.y;
-                P.spos[i] = r.z;
-                P.ssize[i] = r.w;
-            }
-            before += total;
-        }
-        grid.sync(); // ---- B5
-        // ================================================== re-hang: S under v_in, re-rooted at u_in
-        for (long long i = gtid; i < K; i += gsize) { // every path node hangs under its former child
-            const int w = P.snode[i];
-            nd[w].x = i == 0 ? v_in : P.snode[i - 1];
-            nd[w].y = i == 0 ? enter : P.sarc[i - 1];
-            nd[w].w = i == 0 ? n_sub : n_sub - P.ssize[i - 1];
-        }
-        const int lo = a_pos < b_pos + 1 ? a_pos : b_pos + 1;
-        const int hi = a_pos + n_sub > b_pos + 1 ? a_pos + n_sub : b_pos + 1;
-        const int newstart = b_pos < a_pos ? b_pos + 1 : b_pos + 1 - n_sub;
-        const bool cached = K <= ND_PATH_LDS;
-        if (cached) {
-            __syncthreads();
-            for (int i = tid; i < K; i += ND_T) {
-                L.spos[i] = P.spos[i];
-                L.ssize[i] = P.ssize[i];
-            }
-            __syncthreads();
-        }
-        auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
-        auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
-        for (long long t = lo + gtid; t < hi; t += gsize) {
-            const int w = P.order[t];
-            int nt;
-            if (t >= a_pos && t < a_pos + n_sub) {
-                int l2 = 0, h2 = K - 1; // smallest i with t inside the old segment of path node i
-                while (l2 < h2) {
-                    const int mid = (l2 + h2) >> 1;
-                    const int q0 = s_pos(mid);
-                    if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
-                    else l2 = mid + 1;
-                }
-                const int i = l2;
-                int rel, off = 0;
-                if (i == 0) {
-                    rel = static_cast<int>(t) - s_pos(0);
-                } else {
-                    const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i - 1
-                    off = hs;
-                    rel = t < hp ? static_cast<int>(t) - s_pos(i) : (hp - s_pos(i)) + (static_cast<int>(t) - (hp + hs));
-                }
-                nt = newstart + off + rel;
-            } else {
-                nt = b_pos < a_pos ? static_cast<int>(t) + n_sub : static_cast<int>(t) - n_sub;
-            }
-            P.tmp[nt - lo] = w;
-        }
-        grid.sync(); // ---- B6
-        for (long long t = lo + gtid; t < hi; t += gsize) {
-            const int w = P.tmp[t - lo];
-            P.order[t] = w;
-            nd[w].z = static_cast<int>(t);
-        }
-        // (the next iteration's first pass reads flows, capacities and sizes only; its first barrier orders the
-        // positions written here before anything that reads them)
-        (void)u_in;
+        tick(6);
     }
 
     // ====================================================== results
@@ -808,6 +928,12 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         sh->iters = iters;
         sh->flips += flips;
         sh->status = status;
+        for (int k = 0; k < 8; ++k) sh->t_phase[k] = tph[k];
+        sh->sum_cand = sum_cand;
+        sh->sum_sub = sum_sub;
+        sh->sum_path = sum_path;
+        sh->sum_range = sum_range;
+        sh->n_small = n_small;
     }
 }
 
@@ -898,17 +1024,25 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_TRY(pool.get(V, &P.sarc));
     SX_TRY(pool.get(V, &P.spos));
     SX_TRY(pool.get(V, &P.ssize));
+    SX_TRY(pool.get(V, &P.pathidx));
+    SX_HIP(hipMemsetAsync(P.pathidx, 0, sizeof(int32_t) * static_cast<size_t>(V), s));
     for (int k = 0; k < 2; ++k) {
         SX_TRY(pool.get(V > ND_GMAX ? V : ND_GMAX, &P.acc[k]));
         SX_TRY(pool.get(V, &P.anc[k]));
     }
+    hipEvent_t ev[3];
+    for (int k = 0; k < 3; ++k) SX_HIP(hipEventCreate(&ev[k]));
+    SX_HIP(hipEventRecord(ev[0], s));
     // ---- set-up: tree, potentials, dual feasibility by flips, tree flows
     hipLaunchKernelGGL(k_nd_tree, dim3(1), dim3(ND_T), 0, s, P);
     hipLaunchKernelGGL(k_nd_flip, dim3(static_cast<unsigned>((E + 255) / 256)), dim3(256), 0, s, P, xn);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
-    if (sh.status == 5 || sh.not_network) return SX_OK; // not a tree / an uncapacitated arc would have to flip
+    if (sh.status == 5 || sh.not_network) { // not a tree / an uncapacitated arc would have to flip
+        for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
+        return SX_OK;
+    }
     SX_TRY(sx_score_rows_dev(ctx, A, xn, b, nullptr, 0.0, beff, nullptr)); // b - A x_N, sums in stored order
     hipLaunchKernelGGL(k_nd_excess, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, beff);
     hipLaunchKernelGGL(k_nd_initflows, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P);
@@ -925,16 +1059,28 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     P.G = G;
     long long limit = max_iter > 0 ? max_iter : 100 * (V + E);
     void *args[] = {&P, &limit, &feas_tol};
+    SX_HIP(hipEventRecord(ev[1], s));
     SX_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_nd_solve), dim3(static_cast<unsigned>(G)), dim3(ND_T),
                                       args, 0, s));
+    SX_HIP(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_nd_outputs, dim3(static_cast<unsigned>(((E > V ? E : V) + 255) / 256)), dim3(256), 0, s, V, E,
                        P.state, sh.root, vbasis_out, cbasis_out);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
+    const double it_n = sh.iters > 0 ? static_cast<double>(sh.iters) : 1.0;
+    float ms_setup = 0.f, ms_solve = 0.f;
+    (void)hipEventElapsedTime(&ms_setup, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&ms_solve, ev[1], ev[2]);
+    for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
     if (getenv("SX_NS_PROFILE"))
-        fprintf(stderr, "[sx_netdual] V=%lld E=%lld grid=%d iterations=%lld flips=%lld status=%lld\n", (long long)V, (long long)E,
-                G, sh.iters, sh.flips, sh.status);
+        fprintf(stderr, "[sx_netdual] V=%lld E=%lld grid=%d iterations=%lld flips=%lld status=%lld | set-up %.1f ms, solve %.1f ms | "
+                        "us per iteration: pass %.2f wide cut %.2f cut %.2f ratio %.2f publish %.2f (-) %.2f barriers %.2f | per iteration: "
+                        "candidates %.1f, subtree %.1f (alone %.0f%%), path %.1f, positions moved %.1f\n",
+                (long long)V, (long long)E, G, sh.iters, sh.flips, sh.status, ms_setup, ms_solve,
+                sh.t_phase[0] * 0.01 / it_n, sh.t_phase[1] * 0.01 / it_n, sh.t_phase[2] * 0.01 / it_n, sh.t_phase[3] * 0.01 / it_n,
+                sh.t_phase[4] * 0.01 / it_n, sh.t_phase[5] * 0.01 / it_n, sh.t_phase[6] * 0.01 / it_n, sh.sum_cand / it_n,
+                sh.sum_sub / it_n, 100.0 * sh.n_small / it_n, sh.sum_path / it_n, sh.sum_range / it_n);
     result->status = sh.status;
     result->iters = sh.iters;
     result->phase1_iters = sh.flips; // arcs moved bound to bound (at the start and by the ratio test)
