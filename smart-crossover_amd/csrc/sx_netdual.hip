@@ -37,8 +37,9 @@ namespace {
 constexpr int ND_T = 1024;       // lanes per workgroup
 constexpr int ND_W = ND_T / 64;  // waves per workgroup
 constexpr int ND_GMAX = 256;     // workgroups of the cooperative grid (one per CU at most)
-constexpr int ND_PATH_LDS = 2048; // path entries cached in LDS for the new positions
-constexpr int ND_SMALL = 2048;    // subtrees up to this many nodes: workgroup 0 scans the cut alone
+constexpr int ND_PATH_LDS = 1024; // path entries cached in LDS for the new positions
+constexpr int ND_SMALL = 512;     // subtrees up to this many nodes: workgroup 0 scans the cut alone
+constexpr int ND_LCAP = 2048;     // candidates of the ratio test kept in LDS
 constexpr int ST_TREE = 0, ST_LOWER = 1, ST_UPPER = -1;
 constexpr int UNK = -2;
 
@@ -317,6 +318,12 @@ struct NdLds {
     int scan[ND_W];
     int spos[ND_PATH_LDS], ssize[ND_PATH_LDS];
     int s_node[ND_SMALL], s_p0[ND_SMALL], s_off[ND_SMALL]; // workgroup 0: the nodes of a small S and their rows
+    double c_r[ND_LCAP], c_c[ND_LCAP];                     // workgroup 0: candidates of the ratio test
+    int c_j[ND_LCAP];
+    int ccount;
+    // result of the ratio test (wave 0 -> workgroup)
+    int res_enter, res_npush;
+    double res_theta, res_cap, res_remaining;
 };
 
 // larger score wins, then the smaller index; result in every lane
@@ -645,111 +652,221 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         if (g == 0) {
             // marks of the previous path
             for (int i = tid; i < prev_K; i += ND_T) P.pathidx[P.snode[i]] = 0;
+            if (tid == 0) L.ccount = 0;
             if (small) {
                 // the entries of the rows of S's nodes, flattened over the lanes: node t of S owns the entries
-                // [off[t], off[t + 1]) of the flattened list
-                int run = 0;
-                for (int t0 = 0; t0 < n_sub; t0 += ND_T) {
-                    const int t = t0 + tid;
-                    int w = -1, p0 = 0, deg = 0;
-                    if (t < n_sub) {
-                        w = P.order[a_pos + t];
-                        p0 = static_cast<int>(P.rowptr[w]);
-                        deg = static_cast<int>(P.rowptr[w + 1]) - p0;
-                    }
-                    int incl = deg;
+                // [off[t], off[t + 1]) of the flattened list (n_sub <= ND_SMALL <= ND_T: one node per lane)
+                int w = -1, p0 = 0, deg = 0;
+                if (tid < n_sub) {
+                    w = P.order[a_pos + tid];
+                    p0 = static_cast<int>(P.rowptr[w]);
+                    deg = static_cast<int>(P.rowptr[w + 1]) - p0;
+                }
+                int incl = deg;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int up = __shfl_up(incl, o, 64);
-                        if (lane >= o) incl += up;
-                    }
-                    __syncthreads();
-                    if (lane == 63) L.scan[wave] = incl;
-                    __syncthreads();
-                    int before = run, total = 0;
-#pragma unroll
-                    for (int q = 0; q < ND_W; ++q) {
-                        before += q < wave ? L.scan[q] : 0;
-                        total += L.scan[q];
-                    }
-                    if (t < n_sub) {
-                        L.s_node[t] = w;
-                        L.s_p0[t] = p0;
-                        L.s_off[t] = before + incl - deg;
-                    }
-                    run += total;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
                 }
                 __syncthreads();
-                const int T = run;
-                for (int e0 = 0; e0 < T; e0 += ND_T) { // uniform trip count: the slots come from wave ballots
-                    const int e = e0 + tid;
-                    bool elig = false;
-                    int j = -1;
-                    double r = 0.0, c = 0.0;
-                    if (e < T) {
-                        int l2 = 0, h2 = n_sub - 1; // largest t with off[t] <= e
-                        while (l2 < h2) {
-                            const int mid = (l2 + h2 + 1) >> 1;
-                            if (L.s_off[mid] <= e) l2 = mid;
-                            else h2 = mid - 1;
-                        }
-                        const int w = L.s_node[l2];
-                        j = P.rowarc[L.s_p0[l2] + (e - L.s_off[l2])];
-                        const int st = P.state[j];
-                        if (st != ST_TREE) {
-                            const int tl = P.tail[j], hd = P.head[j];
-                            const int o = tl == w ? hd : tl;
-                            if (!in_S(nd[o].z)) consider(j, tl == w, st, elig, r, c);
-                        }
-                    }
-                    append(elig, j, r, c);
+                if (lane == 63) L.scan[wave] = incl;
+                __syncthreads();
+                int before = 0, T = 0;
+#pragma unroll
+                for (int q = 0; q < ND_W; ++q) {
+                    before += q < wave ? L.scan[q] : 0;
+                    T += L.scan[q];
+                }
+                if (tid < n_sub) {
+                    L.s_node[tid] = w;
+                    L.s_p0[tid] = p0;
+                    L.s_off[tid] = before + incl - deg;
                 }
                 __syncthreads();
+                auto append_lds = [&](bool elig, int j, double r, double c) {
+                    const unsigned long long m = __ballot(elig);
+                    if (m == 0ull) return;
+                    int base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(&L.ccount, __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = __shfl(base, 0, 64);
+                    if (elig) {
+                        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < ND_LCAP) {
+                            L.c_j[slot] = j;
+                            L.c_r[slot] = r;
+                            L.c_c[slot] = c;
+                        }
+                        P.cand_j[slot] = j; // the list in memory serves counts beyond ND_LCAP
+                        P.cand_r[slot] = r;
+                        P.cand_c[slot] = c;
+                    }
+                };
+                constexpr int U = 4; // entries per lane and round: their loads are in flight together
+                for (int e0 = 0; e0 < T; e0 += U * ND_T) { // uniform trip count: the slots come from wave ballots
+                    int jj[U], ww[U], st[U], tl[U], hd[U], po[U];
+                    double yt[U], yh[U], cs[U], cp[U];
+                    bool live[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const int e = e0 + k * ND_T + tid;
+                        live[k] = e < T;
+                        jj[k] = 0;
+                        ww[k] = 0;
+                        if (live[k]) {
+                            int l2 = 0, h2 = n_sub - 1; // largest t with off[t] <= e
+                            while (l2 < h2) {
+                                const int mid = (l2 + h2 + 1) >> 1;
+                                if (L.s_off[mid] <= e) l2 = mid;
+                                else h2 = mid - 1;
+                            }
+                            ww[k] = L.s_node[l2];
+                            jj[k] = P.rowarc[L.s_p0[l2] + (e - L.s_off[l2])];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        st[k] = ST_TREE;
+                        tl[k] = hd[k] = 0;
+                        if (live[k]) {
+                            st[k] = P.state[jj[k]];
+                            tl[k] = P.tail[jj[k]];
+                            hd[k] = P.head[jj[k]];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        po[k] = 0;
+                        yt[k] = yh[k] = cs[k] = cp[k] = 0.0;
+                        if (st[k] != ST_TREE) {
+                            po[k] = nd[tl[k] == ww[k] ? hd[k] : tl[k]].z;
+                            yt[k] = P.y[tl[k]];
+                            yh[k] = P.y[hd[k]];
+                            cs[k] = P.cost[jj[k]];
+                            cp[k] = P.cap[jj[k]];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        bool elig = false;
+                        if (st[k] != ST_TREE && !in_S(po[k])) {
+                            const bool tail_in = tl[k] == ww[k];
+                            elig = tau > 0 ? (tail_in ? st[k] == ST_LOWER : st[k] == ST_UPPER)
+                                           : (tail_in ? st[k] == ST_UPPER : st[k] == ST_LOWER);
+                        }
+                        const double rc = (cs[k] - yt[k]) + yh[k];
+                        append_lds(elig, jj[k], fabs(rc), cp[k]);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) sh->cand_count = L.ccount;
             }
             tick(2);
             // ---- ratio test with bound flipping: candidates in ascending (|reduced cost|, arc)
-            const int C = sh->cand_count;
+            __syncthreads();
+            const int C = small ? L.ccount : sh->cand_count;
             sum_cand += C;
-            double r0 = 0.0, c0 = 0.0; // this lane's first candidate, kept in registers over the rounds
-            int j0 = -1;
-            if (tid < C) {
-                r0 = P.cand_r[tid];
-                c0 = P.cand_c[tid];
-                j0 = P.cand_j[tid];
+            if (!small && C <= ND_LCAP) { // the wide scan left its list in memory
+                for (int i = tid; i < C; i += ND_T) {
+                    L.c_j[i] = P.cand_j[i];
+                    L.c_r[i] = P.cand_r[i];
+                    L.c_c[i] = P.cand_c[i];
+                }
+                __syncthreads();
             }
             double remaining = delta, last_r = -1.0;
             int last_j = -1, npush = 0, enter = -1;
             double theta = 0.0, cap_e = 0.0;
-            while (true) {
-                double r = 0.0, c = 0.0;
-                int j = -1;
-                if (j0 >= 0 && (r0 > last_r || (r0 == last_r && j0 > last_j))) {
-                    r = r0;
-                    c = c0;
-                    j = j0;
-                }
-                for (int i = tid + ND_T; i < C; i += ND_T) {
-                    const double r2 = P.cand_r[i];
-                    const int j2 = P.cand_j[i];
-                    if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
-                        r = r2;
-                        j = j2;
-                        c = P.cand_c[i];
+            if (C <= ND_LCAP) { // one wave, candidates in LDS: a round is a strided scan and a wave reduction
+                if (wave == 0) {
+                    while (true) {
+                        double r = 0.0, c = 0.0;
+                        int j = -1;
+                        for (int i = lane; i < C; i += 64) {
+                            const double r2 = L.c_r[i];
+                            const int j2 = L.c_j[i];
+                            if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
+                                r = r2;
+                                j = j2;
+                                c = L.c_c[i];
+                            }
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const double r2 = __shfl_xor(r, o, 64), c2 = __shfl_xor(c, o, 64);
+                            const int j2 = __shfl_xor(j, o, 64);
+                            if (j2 >= 0 && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
+                                r = r2;
+                                j = j2;
+                                c = c2;
+                            }
+                        }
+                        if (j < 0) break;
+                        if (c < remaining) {
+                            if (lane == 0) P.tmp[npush] = j;
+                            ++npush;
+                            remaining = remaining - c;
+                            last_r = r;
+                            last_j = j;
+                        } else {
+                            enter = j;
+                            theta = r;
+                            cap_e = c;
+                            break;
+                        }
+                    }
+                    if (lane == 0) {
+                        L.res_enter = enter;
+                        L.res_npush = npush;
+                        L.res_theta = theta;
+                        L.res_cap = cap_e;
+                        L.res_remaining = remaining;
                     }
                 }
-                nd_argmin(L, r, j, c);
-                if (j < 0) break; // every candidate passed and the arc is still infeasible: no entering arc
-                if (c < remaining) {
-                    if (tid == 0) P.tmp[npush] = j;
-                    ++npush;
-                    remaining = remaining - c;
-                    last_r = r;
-                    last_j = j;
-                } else {
-                    enter = j;
-                    theta = r;
-                    cap_e = c;
-                    break;
+                __syncthreads();
+                enter = L.res_enter;
+                npush = L.res_npush;
+                theta = L.res_theta;
+                cap_e = L.res_cap;
+                remaining = L.res_remaining;
+            } else {
+                double r0 = 0.0, c0 = 0.0; // this lane's first candidate, kept in registers over the rounds
+                int j0 = -1;
+                if (tid < C) {
+                    r0 = P.cand_r[tid];
+                    c0 = P.cand_c[tid];
+                    j0 = P.cand_j[tid];
+                }
+                while (true) {
+                    double r = 0.0, c = 0.0;
+                    int j = -1;
+                    if (j0 >= 0 && (r0 > last_r || (r0 == last_r && j0 > last_j))) {
+                        r = r0;
+                        c = c0;
+                        j = j0;
+                    }
+                    for (int i = tid + ND_T; i < C; i += ND_T) {
+                        const double r2 = P.cand_r[i];
+                        const int j2 = P.cand_j[i];
+                        if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
+                            r = r2;
+                            j = j2;
+                            c = P.cand_c[i];
+                        }
+                    }
+                    nd_argmin(L, r, j, c);
+                    if (j < 0) break; // every candidate passed and the arc is still infeasible: no entering arc
+                    if (c < remaining) {
+                        if (tid == 0) P.tmp[npush] = j;
+                        ++npush;
+                        remaining = remaining - c;
+                        last_r = r;
+                        last_j = j;
+                    } else {
+                        enter = j;
+                        theta = r;
+                        cap_e = c;
+                        break;
+                    }
                 }
             }
             __syncthreads();
