@@ -225,12 +225,11 @@ def crossover_network():
     return out
 
 
-def crossover_mcf(V: int = 4096, E: int = 32768):
+def crossover_mcf(V: int = 4096, E: int = 32768, solvers=("HIP", "HGS"), repeats: int = 2):
     """BASELINE metric, part 'crossover wall-time (ms)', min-cost-flow case: the whole ``network_crossover`` call
-    (CNET_MCF) on a V-node / E-arc network of config 4's family, once with the re-solves on the device (solver
-    'HIP': every round is a network LP with a warm tree basis -> network simplex K16n) and once in HiGHS on the
-    host cores.  Config 4 itself (V = 2^17, E = 2^20) is in profiles/r02/network_simplex.md: 94 s with HiGHS,
-    not finished after 18 minutes on the device."""
+    (CNET_MCF) on a V-node / E-arc network of config 4's family (V = 2^17, E = 2^20 is config 4 itself), with the
+    re-solves on the device (solver 'HIP': every round is a network LP with a warm tree basis -> dual network
+    simplex K16d on the whole GPU) and, when asked for, in HiGHS on the host cores.  Host memory to host memory."""
     import io
     from contextlib import redirect_stdout
     from smart_crossover.formats import MinCostFlow
@@ -238,8 +237,10 @@ def crossover_mcf(V: int = 4096, E: int = 32768):
     out = {"workload": f"min-cost flow V = {V}, E = {E} (workloads.mcf, seed 3), method cnet_mcf, host memory to host memory"}
     costs = {}
     for solver, key in (("HIP", "gpu_resident_ms"), ("HGS", "host_solver_ms")):
+        if solver not in solvers:
+            continue
         times = []
-        for _ in range(2):
+        for _ in range(repeats if solver == "HIP" else 1):
             inst = workloads.mcf(V, E, 3)
             mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
             t0 = time.perf_counter()
@@ -247,12 +248,16 @@ def crossover_mcf(V: int = 4096, E: int = 32768):
                 res = network_crossover(inst.x.copy(), mcf=mcf, method="cnet_mcf", solver=solver)
             times.append((time.perf_counter() - t0) * 1e3)
         costs[solver] = float(inst.c @ res.x[:E])
+        flow_violation = float(np.abs(inst.A @ res.x[:E] - inst.b).max())
+        if flow_violation > 1e-6 * (1 + float(np.abs(inst.b).max())) or res.x[:E].min() < -1e-9 or (res.x[:E] - inst.u).max() > 1e-9:
+            raise SystemExit(f"bench: network crossover ({solver}) returned an infeasible flow")
         out[key] = float(times[-1])
         out[f"simplex_iterations_{solver}"] = int(res.iter_count)
-    if abs(costs["HIP"] - costs["HGS"]) > 1e-9 * (1 + abs(costs["HGS"])):
+    if len(costs) == 2 and abs(costs["HIP"] - costs["HGS"]) > 1e-9 * (1 + abs(costs["HGS"])):
         raise SystemExit("bench: device and HiGHS re-solves disagree on the optimal flow cost")
-    out["optimal_cost"] = costs["HGS"]
-    out["speedup"] = out["host_solver_ms"] / out["gpu_resident_ms"]
+    out["optimal_cost"] = costs.get("HGS", costs.get("HIP"))
+    if len(costs) == 2:
+        out["speedup"] = out["host_solver_ms"] / out["gpu_resident_ms"]
     return out
 
 
@@ -286,6 +291,9 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=0,
                     help="also time this many iterations of the column-sharded projector CG (one m-vector all-reduce per "
                          "iteration over RCCL at N > 1): reported under 'sharded_cg', not part of the step")
+    ap.add_argument("--c4-highs", action="store_true",
+                    help="time config 4's network crossover with the re-solves in HiGHS too (94 s on the box's host cores; "
+                         "without it the line quotes profiles/r02/netdual_c4_highs.jsonl)")
     ap.add_argument("--highs-seconds", type=float, default=120.0,
                     help="time limit of the HiGHS re-solve timed beside the device crossover of config 2 (0: skip)")
     args = ap.parse_args()
@@ -594,11 +602,22 @@ def main():
             for a in (dC, dR):
                 a.free()
         net_c3, net_mcf = crossover_network(), crossover_mcf()
+        net_c4 = crossover_mcf(2 ** 17, 2 ** 20, solvers=("HIP", "HGS") if args.c4_highs else ("HIP",), repeats=1)
+        if not args.c4_highs:   # the HiGHS leg as recorded on one of the pool's boxes (same instance, same code path)
+            rec_path = os.path.join(ROOT, "profiles", "r02", "netdual_c4_highs.jsonl")
+            if os.path.exists(rec_path):
+                rec = json.loads(open(rec_path).readline())
+                net_c4["host_solver_ms_recorded"] = rec["wall_ms"]
+                net_c4["simplex_iterations_HGS_recorded"] = rec["simplex_iterations"]
+                net_c4["recorded_in"] = "profiles/r02/netdual_c4_highs.jsonl (python bench.py --c4-highs re-measures it)"
+                if abs(rec["cost"] - net_c4["optimal_cost"]) > 1e-9 * (1 + abs(rec["cost"])):
+                    raise SystemExit("bench: the device's config-4 optimum differs from the recorded HiGHS optimum")
         crossover = {"lp_c2_host_path": crossover_host_path(args.cpu_seconds),
                      "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
                      "lp_c5_get_perturb_problem": crossover_lp_c5(),
                      "network_c3": net_c3,
-                     "network_mcf_4096": net_mcf}
+                     "network_mcf_4096": net_mcf,
+                     "network_c4": net_c4}
 
     if rank == 0:
         out = {

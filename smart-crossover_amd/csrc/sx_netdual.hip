@@ -100,6 +100,8 @@ struct NdProblem {
     double *acc[2];
     int32_t *anc[2];
     NdShared *sh;
+    unsigned long long *bar; // grid barrier: arrivals
+    int nap_short, nap_long; // naps between polls: after a pass / while workgroup 0 decides
 };
 
 // ------------------------------------------------------------------ arcs from the columns of A
@@ -310,6 +312,24 @@ __global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
     P.flow[r.y] = (P.tail[r.y] == w) ? s : -s;
 }
 
+// ------------------------------------------------------------------ grid barrier
+// Arrival counter that only grows (epoch e is complete at (e + 1) * G arrivals); the waiting workgroups poll it
+// with naps in between: while workgroup 0 decides alone, 128 workgroups polling the same line without a pause
+// slow its dependent loads by a factor of two (profiles/r02/netdual.md).  Release / acquire at agent scope make
+// the passes' plain stores visible across the XCDs' L2s, as the cooperative-groups barrier does.
+__device__ __forceinline__ void nd_barrier(unsigned long long *counter, unsigned long long &epoch, int G, int naps) {
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        const unsigned long long target = epoch * static_cast<unsigned long long>(G);
+        __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks
+        }
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ workgroup reductions
 struct NdLds {
     double d[ND_W];
@@ -416,8 +436,8 @@ __device__ __forceinline__ int nd_sum(NdLds &L, int v) {
 //          (1 % of the iterations) has its cut scanned by all workgroups first, one more barrier
 //   ----   barrier
 __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_iters, double feas_tol) {
-    cg::grid_group grid = cg::this_grid();
     __shared__ NdLds L;
+    unsigned long long epoch = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = P.G, g = blockIdx.x;
     const int V = P.V;
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             if (g == 0) sh->cand_count = 0;
         }
         tick(0);
-        grid.sync(); // ---- B1
+        nd_barrier(P.bar, epoch, G, P.nap_short); // ---- B1
         tick(6);
         bs = 0.0;
         bn = 0x7fffffff;
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 }
             }
             tick(1);
-            grid.sync(); // ---- B2 (large subtrees only)
+            nd_barrier(P.bar, epoch, G, P.nap_short); // ---- B2 (large subtrees only)
             tick(6);
         }
         // ================================================== workgroup 0 decides
@@ -778,18 +798,46 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             double theta = 0.0, cap_e = 0.0;
             if (C <= ND_LCAP) { // one wave, candidates in LDS: a round is a strided scan and a wave reduction
                 if (wave == 0) {
-                    while (true) {
-                        double r = 0.0, c = 0.0;
-                        int j = -1;
+                    // every lane keeps the four smallest of its strided share in registers, sorted; a round pops
+                    // the smallest head of the wave.  A lane that runs dry while it has more re-reads its share
+                    double tr[4], tcap[4];
+                    int tj[4];
+                    auto refill = [&](double lr, int lj) { // the lane's four smallest candidates above (lr, lj)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            tj[k] = -1;
+                            tr[k] = 0.0;
+                            tcap[k] = 0.0;
+                        }
+                        int seen = 0;
                         for (int i = lane; i < C; i += 64) {
-                            const double r2 = L.c_r[i];
-                            const int j2 = L.c_j[i];
-                            if ((r2 > last_r || (r2 == last_r && j2 > last_j)) && (j < 0 || r2 < r || (r2 == r && j2 < j))) {
-                                r = r2;
-                                j = j2;
-                                c = L.c_c[i];
+                            double r2 = L.c_r[i];
+                            int j2 = L.c_j[i];
+                            if (r2 > lr || (r2 == lr && j2 > lj)) {
+                                double c2 = L.c_c[i];
+                                ++seen;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { // insertion: the larger one travels on
+                                    const bool first = j2 >= 0 && (tj[k] < 0 || r2 < tr[k] || (r2 == tr[k] && j2 < tj[k]));
+                                    if (first) {
+                                        const double rr = tr[k], cc = tcap[k];
+                                        const int jj2 = tj[k];
+                                        tr[k] = r2;
+                                        tcap[k] = c2;
+                                        tj[k] = j2;
+                                        r2 = rr;
+                                        c2 = cc;
+                                        j2 = jj2;
+                                    }
+                                }
                             }
                         }
+                        return seen > 4;
+                    };
+                    bool more = refill(-1.0, -1);
+                    while (true) {
+                        double r = tr[0], c = tcap[0];
+                        int j = tj[0];
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) {
                             const double r2 = __shfl_xor(r, o, 64), c2 = __shfl_xor(c, o, 64);
@@ -800,13 +848,24 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                                 c = c2;
                             }
                         }
-                        if (j < 0) break;
+                        if (j < 0) break; // every candidate passed and the arc is still infeasible: no entering arc
                         if (c < remaining) {
                             if (lane == 0) P.tmp[npush] = j;
                             ++npush;
                             remaining = remaining - c;
                             last_r = r;
                             last_j = j;
+                            const bool mine = tj[0] == j;
+                            if (mine) { // pop
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) {
+                                    tr[k] = tr[k + 1];
+                                    tcap[k] = tcap[k + 1];
+                                    tj[k] = tj[k + 1];
+                                }
+                                tj[3] = -1;
+                                if (tj[0] < 0 && more) more = refill(r, j);
+                            }
                         } else {
                             enter = j;
                             theta = r;
@@ -965,12 +1024,12 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             if (tid == 0) sh->dec = N;
             tick(4);
         }
-        grid.sync(); // ---- B3
+        nd_barrier(P.bar, epoch, G, P.nap_long); // ---- B3
         tick(6);
     }
 
     // ====================================================== results
-    grid.sync();
+    nd_barrier(P.bar, epoch, G, P.nap_short);
     // potentials once more from the tree itself (pointer jumping): the duals handed back are the tree's own
     for (long long w = gtid; w < V; w += gsize) {
         const int4 r = nd[w];
@@ -983,7 +1042,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         P.acc[0][w] = c;
         P.anc[0][w] = up;
     }
-    grid.sync();
+    nd_barrier(P.bar, epoch, G, P.nap_short);
     int cur = 0;
     for (int round = 0; round < 32; ++round) {
         int moved = 0;
@@ -996,11 +1055,11 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         }
         moved = nd_sum(L, moved);
         if (tid == 0) P.part_cnt[g] = moved;
-        grid.sync();
+        nd_barrier(P.bar, epoch, G, P.nap_short);
         int any = tid < G ? P.part_cnt[tid] : 0;
         any = nd_sum(L, any);
         cur = 1 - cur;
-        grid.sync(); // part_cnt is rewritten in the next round
+        nd_barrier(P.bar, epoch, G, P.nap_short); // part_cnt is rewritten in the next round
         if (!any) break;
     }
     for (long long w = gtid; w < V; w += gsize) P.y[w] = P.acc[cur][w];
@@ -1033,7 +1092,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         P.part_s[g] = tot;
         P.acc[1 - cur][g] = wm; // (free again)
     }
-    grid.sync();
+    nd_barrier(P.bar, epoch, G, P.nap_short);
     if (g == 0 && tid == 0) {
         double tot = 0.0, wm = 0.0;
         for (int k = 0; k < G; ++k) {
@@ -1167,13 +1226,20 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     int per_cu = 0;
     SX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_nd_solve, ND_T, 0));
     int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    int64_t want = ((V > E / 8 ? V : E / 8) + ND_T - 1) / ND_T;
+    int64_t want = (V + 2 * ND_T - 1) / (2 * ND_T); // two nodes per lane in the pass: fewer workgroups at the barriers pay for it
     int G = static_cast<int>(want < 1 ? 1 : want);
     if (ctx->opt_nd_grid > 0) G = ctx->opt_nd_grid;
     if (G > ND_GMAX) G = ND_GMAX;
     if (G > per_cu * cus) G = per_cu * cus;
     if (G < 1) G = 1;
     P.G = G;
+    SX_TRY(pool.get(1, &P.bar));
+    SX_HIP(hipMemsetAsync(P.bar, 0, sizeof(unsigned long long), s));
+    {
+        static const char *e1 = getenv("SX_ND_NAP_SHORT"), *e2 = getenv("SX_ND_NAP_LONG"); // experiments
+        P.nap_short = e1 ? atoi(e1) : 0;
+        P.nap_long = e2 ? atoi(e2) : 2;
+    }
     long long limit = max_iter > 0 ? max_iter : 100 * (V + E);
     void *args[] = {&P, &limit, &feas_tol};
     SX_HIP(hipEventRecord(ev[1], s));
