@@ -142,6 +142,56 @@ def test_config3_network_crossover_device_resident_equals_host_solver(method):
     assert costs["HIP"] == pytest.approx(costs["HGS"], rel=1e-9)
 
 
+def test_config4_network_crossover_on_the_device():
+    """BASELINE config 4 (min-cost flow, 131,072 nodes, 1,048,576 arcs) through the whole CNET_MCF crossover with
+    every re-solve on the device (dual network simplex K16d; reference network_methods/algorithms.py:14-77 with
+    net_manager.py:211-222).  HiGHS needs 96 s for its leg, so it is not re-run here: its optimum is the recorded
+    one (tests/golden/c4_cnet_mcf.json: two independent HiGHS-backed runs, profiles/r01 and profiles/r02) and the
+    rest are solver-independent certificates -- conservation, bounds, a spanning-tree basis, dual feasibility."""
+    import io
+    import json
+    import os
+    from contextlib import redirect_stdout
+    import scipy.sparse as sp
+    from conftest import ROOT
+    from smart_crossover.formats import MinCostFlow
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller import hip as hipmod
+    inst = workloads.config4()
+    V, E = inst.A.shape
+    mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
+    used = []
+    orig = hipmod.HipCaller._solve
+
+    def spy(self):
+        orig(self)
+        used.append((self.solved_by, int(self._res.iters)))
+
+    hipmod.HipCaller._solve = spy
+    try:
+        with redirect_stdout(io.StringIO()) as text:
+            out = network_crossover(inst.x.copy(), mcf=mcf, method="cnet_mcf", solver="HIP")
+    finally:
+        hipmod.HipCaller._solve = orig
+    assert "Column generation fails" not in text.getvalue()
+    assert used and all(how == "netdual" for how, _ in used)
+    x = out.x[:E]
+    assert np.abs(inst.A @ x - inst.b).max() <= 1e-7 * (1 + np.abs(inst.b).max())
+    assert x.min() >= -1e-8 and (x - inst.u).max() <= 1e-8          # tree arcs: within the solver's 1e-9 of a bound
+    assert np.abs(out.x[E:E + V]).max() < 1e-8                       # no flow left on the artificial arcs
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "c4_cnet_mcf.json")))
+    assert float(inst.c @ x) == pytest.approx(want["optimal_cost_highs"], rel=1e-9)
+    assert sum(it for _, it in used) == out.iter_count
+    # the basis handed back: a spanning tree of the extended network (V + 1 nodes) + the root row
+    vb, cb = out.basis.vbasis, out.basis.cbasis
+    assert np.count_nonzero(vb == 0) == V and np.count_nonzero(cb == 0) == 1
+    assert np.all(x[vb[:E] == -1] == 0.0) and np.all(x[vb[:E] == -2] == inst.u[vb[:E] == -2])
+    basic = np.flatnonzero(vb[:E] == 0)
+    g = sp.coo_matrix((np.ones(basic.size), (inst.tail[basic], inst.head[basic])), shape=(V, V))
+    ncomp, _ = sp.csgraph.connected_components(g, directed=False)
+    assert ncomp == V - basic.size                                  # the basic original arcs are a forest
+
+
 def test_config2_perturbation_crossover_end_to_end_on_the_device():
     """BASELINE config 2 (2e4 x 1e5, 2e6 entries) through the crossover proper, all on the GPU: from the
     interior point (x, y) to a vertex of the perturbed sub-problem with its basis -- get_perturb_problem, then
