@@ -40,6 +40,7 @@ constexpr int ND_GMAX = 256;     // workgroups of the cooperative grid (one per 
 constexpr int ND_PATH_LDS = 1024; // path entries cached in LDS for the new positions
 constexpr int ND_SMALL = 512;     // subtrees up to this many nodes: workgroup 0 scans the cut alone
 constexpr int ND_LCAP = 2048;     // candidates of the ratio test kept in LDS
+constexpr int ND_PUSH_LDS = 64;   // moved arcs of a decision cached in LDS for the pass
 constexpr int ST_TREE = 0, ST_LOWER = 1, ST_UPPER = -1;
 constexpr int UNK = -2;
 
@@ -78,6 +79,9 @@ struct NdProblem {
     int G; // workgroups
     const int64_t *rowptr; // CSR of A: row v -> its arcs
     const int32_t *rowarc;
+    int32_t *rowother;     // per CSR entry: the arc's other end o, or ~o when this row is the arc's head
+    int2 *noderec;         // per node: {first CSR entry, degree}
+    int2 *ordrec;          // the same by preorder position (kept with order[])
     int32_t *tail, *head;
     const double *cost, *cap;
     double *flow;
@@ -254,6 +258,25 @@ __global__ __launch_bounds__(ND_T) void k_nd_tree(NdProblem P) {
     }
 }
 
+// adjacency side arrays: the other end of every CSR entry (one wave per row), the rows' extents
+__global__ __launch_bounds__(256) void k_nd_adjacency(NdProblem P) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    if (w >= P.V) return;
+    const int64_t p0 = P.rowptr[w], p1 = P.rowptr[w + 1];
+    if (lane == 0) P.noderec[w] = make_int2(static_cast<int>(p0), static_cast<int>(p1 - p0));
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+        const int j = P.rowarc[p];
+        const int t = P.tail[j], h = P.head[j];
+        P.rowother[p] = t == w ? h : ~t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nd_ordrec(NdProblem P) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.V) P.ordrec[t] = P.noderec[P.order[t]];
+}
+
 // dual feasibility by moving arcs to their other bound; x_N for the right-hand side
 __global__ __launch_bounds__(256) void k_nd_flip(NdProblem P, double *__restrict__ xn) {
     const long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -341,6 +364,8 @@ struct NdLds {
     double c_r[ND_LCAP], c_c[ND_LCAP];                     // workgroup 0: candidates of the ratio test
     int c_j[ND_LCAP];
     int ccount;
+    int p_pt[ND_PUSH_LDS], p_ph[ND_PUSH_LDS]; // the decision's moved arcs
+    double p_d[ND_PUSH_LDS];
     // result of the ratio test (wave 0 -> workgroup)
     int res_enter, res_npush;
     double res_theta, res_cap, res_remaining;
@@ -466,103 +491,146 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             break;
         }
         const bool cached = D.has && D.K <= ND_PATH_LDS;
-        if (cached) {
-            __syncthreads();
-            for (int i = tid; i < D.K; i += ND_T) {
-                L.spos[i] = P.spos[i];
-                L.ssize[i] = P.ssize[i];
-            }
-            __syncthreads();
-        }
-        auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
-        auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
+        const bool pcached = D.has && D.npush <= ND_PUSH_LDS;
         double bs = 0.0;
         int bn = 0x7fffffff;
-        for (long long w = gtid; w < V; w += gsize) {
-            int4 r = nd[w];
-            if (D.has) {
-                const bool inside = r.z >= D.a_pos && r.z < D.a_pos + D.n_sub;
-                const int pi = inside ? P.pathidx[w] : 0; // 1 + index on the path u_in .. v
-                if (w != root) {
-                    // the arc that hangs w after the re-hang, and the subtree it closed before: a path node takes
-                    // over the arc of the path node below it
-                    int arc = r.y, iz = r.z, iw = r.w, owner = static_cast<int>(w);
-                    if (pi > 0) {
-                        if (pi == D.K) P.flow[r.y] = D.to_lower ? 0.0 : P.cap[r.y]; // the leaving arc lands on its bound
-                        if (pi == 1) {
-                            arc = -1; // the entering arc: workgroup 0 set its flow
-                        } else {
-                            arc = P.sarc[pi - 2];
-                            iz = s_pos(pi - 2);
-                            iw = s_size(pi - 2);
-                            owner = P.snode[pi - 2];
-                        }
+        for (long long rb = 0; rb < V; rb += 2 * gsize) { // the same trip count in every lane: barriers inside
+            const long long base = rb + gtid;
+            // two nodes per lane and round; everything that depends only on the node is requested before the
+            // decision is looked at, the flow and capacity of its arc right behind -- two levels of loads
+            long long wk[2] = {base, base + gsize};
+            int4 rk[2];
+            int pik[2];
+            int2 reck[2];
+            double fk[2], ck[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const long long w = wk[k] < V ? wk[k] : 0;
+                rk[k] = nd[w];
+                pik[k] = P.pathidx[w];
+                reck[k] = P.noderec[w];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                fk[k] = ck[k] = 0.0;
+                if (rk[k].y >= 0) {
+                    fk[k] = P.flow[rk[k].y];
+                    ck[k] = P.cap[rk[k].y];
+                }
+            }
+            if (rb == 0 && (cached || pcached)) { // (first round only) the decision's lists -> LDS
+                __syncthreads();
+                if (cached)
+                    for (int i = tid; i < D.K; i += ND_T) {
+                        L.spos[i] = P.spos[i];
+                        L.ssize[i] = P.ssize[i];
                     }
-                    if (arc >= 0) {
-                        double d = 0.0;
-                        bool any = false;
-                        for (int i = 0; i < D.npush; ++i) { // the subtree separates the ends of a moved arc
-                            const int pt = P.push_pt[i], ph = P.push_ph[i];
-                            const bool ti = pt >= iz && pt < iz + iw, hi = ph >= iz && ph < iz + iw;
-                            if (ti != hi) {
-                                const double x = P.push_d[i];
-                                d = d + (hi ? x : -x);
-                                any = true;
+                if (pcached && tid < D.npush) {
+                    L.p_pt[tid] = P.push_pt[tid];
+                    L.p_ph[tid] = P.push_ph[tid];
+                    L.p_d[tid] = P.push_d[tid];
+                }
+                __syncthreads();
+            }
+            auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
+            auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const long long w = wk[k];
+                if (w >= V) continue;
+                int4 r = rk[k];
+                double f = fk[k], c = ck[k];
+                if (D.has) {
+                    const bool inside = r.z >= D.a_pos && r.z < D.a_pos + D.n_sub;
+                    const int pi = inside ? pik[k] : 0; // 1 + index on the path u_in .. v
+                    if (w != root) {
+                        // the arc that hangs w after the re-hang, and the subtree it closed before: a path node
+                        // takes over the arc of the path node below it
+                        int arc = r.y, iz = r.z, iw = r.w, owner = static_cast<int>(w);
+                        if (pi > 0) {
+                            if (pi == D.K) P.flow[r.y] = D.to_lower ? 0.0 : c; // the leaving arc lands on its bound
+                            if (pi == 1) {
+                                arc = -1; // the entering arc: workgroup 0 set its flow
+                                f = P.flow[D.enter];
+                                c = P.cap[D.enter];
+                            } else {
+                                arc = P.sarc[pi - 2];
+                                iz = s_pos(pi - 2);
+                                iw = s_size(pi - 2);
+                                owner = P.snode[pi - 2];
+                                f = P.flow[arc];
+                                c = P.cap[arc];
                             }
                         }
-                        if (any) P.flow[arc] = P.flow[arc] + ((P.tail[arc] == owner) ? d : -d);
-                    }
-                }
-                int4 q = r;
-                if (pi > 0) {
-                    q.x = pi == 1 ? D.v_in : P.snode[pi - 2];
-                    q.y = pi == 1 ? D.enter : P.sarc[pi - 2];
-                    q.w = pi == 1 ? D.n_sub : D.n_sub - s_size(pi - 2);
-                } else if (!inside) {
-                    const bool anc_v = r.z <= D.a_pos && D.a_pos < r.z + r.w;
-                    const bool anc_in = r.z <= D.b_pos && D.b_pos < r.z + r.w;
-                    if (anc_v != anc_in) q.w = r.w + (anc_in ? D.n_sub : -D.n_sub);
-                }
-                if (inside) P.y[w] = P.y[w] + D.dy;
-                if (r.z >= D.lo && r.z < D.hi) { // S moves right behind v_in, re-rooted at u_in
-                    const int t = r.z;
-                    int nt;
-                    if (inside) {
-                        int l2 = 0, h2 = D.K - 1; // smallest i with t inside the old segment of path node i
-                        while (l2 < h2) {
-                            const int mid = (l2 + h2) >> 1;
-                            const int q0 = s_pos(mid);
-                            if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
-                            else l2 = mid + 1;
+                        if (arc >= 0) {
+                            double d = 0.0;
+                            bool any = false;
+                            for (int i = 0; i < D.npush; ++i) { // the subtree separates the ends of a moved arc
+                                const int pt = pcached ? L.p_pt[i] : P.push_pt[i], ph = pcached ? L.p_ph[i] : P.push_ph[i];
+                                const bool ti = pt >= iz && pt < iz + iw, hi = ph >= iz && ph < iz + iw;
+                                if (ti != hi) {
+                                    const double x = pcached ? L.p_d[i] : P.push_d[i];
+                                    d = d + (hi ? x : -x);
+                                    any = true;
+                                }
+                            }
+                            if (any) {
+                                f = f + ((P.tail[arc] == owner) ? d : -d);
+                                P.flow[arc] = f;
+                            }
                         }
-                        const int i = l2;
-                        int rel, off = 0;
-                        if (i == 0) {
-                            rel = t - s_pos(0);
+                    }
+                    int4 q = r;
+                    if (pi > 0) {
+                        q.x = pi == 1 ? D.v_in : P.snode[pi - 2];
+                        q.y = pi == 1 ? D.enter : P.sarc[pi - 2];
+                        q.w = pi == 1 ? D.n_sub : D.n_sub - s_size(pi - 2);
+                    } else if (!inside) {
+                        const bool anc_v = r.z <= D.a_pos && D.a_pos < r.z + r.w;
+                        const bool anc_in = r.z <= D.b_pos && D.b_pos < r.z + r.w;
+                        if (anc_v != anc_in) q.w = r.w + (anc_in ? D.n_sub : -D.n_sub);
+                    }
+                    if (inside) P.y[w] = P.y[w] + D.dy;
+                    if (r.z >= D.lo && r.z < D.hi) { // S moves right behind v_in, re-rooted at u_in
+                        const int t = r.z;
+                        int nt;
+                        if (inside) {
+                            int l2 = 0, h2 = D.K - 1; // smallest i with t inside the old segment of path node i
+                            while (l2 < h2) {
+                                const int mid = (l2 + h2) >> 1;
+                                const int q0 = s_pos(mid);
+                                if (t >= q0 && t < q0 + s_size(mid)) h2 = mid;
+                                else l2 = mid + 1;
+                            }
+                            const int i = l2;
+                            int rel, off = 0;
+                            if (i == 0) {
+                                rel = t - s_pos(0);
+                            } else {
+                                const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i - 1
+                                off = hs;
+                                rel = t < hp ? t - s_pos(i) : (hp - s_pos(i)) + (t - (hp + hs));
+                            }
+                            nt = D.newstart + off + rel;
                         } else {
-                            const int hp = s_pos(i - 1), hs = s_size(i - 1); // the hole: the old segment of path node i - 1
-                            off = hs;
-                            rel = t < hp ? t - s_pos(i) : (hp - s_pos(i)) + (t - (hp + hs));
+                            nt = D.b_pos < D.a_pos ? t + D.n_sub : t - D.n_sub;
                         }
-                        nt = D.newstart + off + rel;
-                    } else {
-                        nt = D.b_pos < D.a_pos ? t + D.n_sub : t - D.n_sub;
+                        q.z = nt;
+                        P.order[nt] = static_cast<int>(w);
+                        P.ordrec[nt] = reck[k];
                     }
-                    q.z = nt;
-                    P.order[nt] = static_cast<int>(w);
+                    if (q.x != r.x || q.y != r.y || q.z != r.z || q.w != r.w) nd[w] = q;
+                    r = q;
                 }
-                nd[w] = q;
-                r = q;
-            }
-            if (w != root) {
-                const double f = P.flow[r.y], c = P.cap[r.y];
-                const double lo = -f, hi = f - c;
-                const double viol = lo > hi ? lo : hi;
-                if (viol > feas_tol) {
-                    const double s = (viol * viol) / static_cast<double>(r.w);
-                    if (s > bs || (s == bs && w < bn)) {
-                        bs = s;
-                        bn = static_cast<int>(w);
+                if (w != root) {
+                    const double lo = -f, hi = f - c;
+                    const double viol = lo > hi ? lo : hi;
+                    if (viol > feas_tol) {
+                        const double sc = (viol * viol) / static_cast<double>(r.w);
+                        if (sc > bs || (sc == bs && w < bn)) {
+                            bs = sc;
+                            bn = static_cast<int>(w);
+                        }
                     }
                 }
             }
@@ -679,8 +747,9 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 int w = -1, p0 = 0, deg = 0;
                 if (tid < n_sub) {
                     w = P.order[a_pos + tid];
-                    p0 = static_cast<int>(P.rowptr[w]);
-                    deg = static_cast<int>(P.rowptr[w + 1]) - p0;
+                    const int2 rec = P.ordrec[a_pos + tid];
+                    p0 = rec.x;
+                    deg = rec.y;
                 }
                 int incl = deg;
 #pragma unroll
@@ -723,15 +792,18 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 };
                 constexpr int U = 4; // entries per lane and round: their loads are in flight together
                 for (int e0 = 0; e0 < T; e0 += U * ND_T) { // uniform trip count: the slots come from wave ballots
-                    int jj[U], ww[U], st[U], tl[U], hd[U], po[U];
-                    double yt[U], yh[U], cs[U], cp[U];
+                    // three levels of dependent loads: (entry -> arc, other end, y of this end) -> (state, cost,
+                    // capacity, position and y of the other end) -> candidate
+                    int jj[U], oo[U], st[U], po[U];
+                    double yw[U], yo[U], cs[U], cp[U];
                     bool live[U];
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         const int e = e0 + k * ND_T + tid;
                         live[k] = e < T;
                         jj[k] = 0;
-                        ww[k] = 0;
+                        oo[k] = 0;
+                        yw[k] = 0.0;
                         if (live[k]) {
                             int l2 = 0, h2 = n_sub - 1; // largest t with off[t] <= e
                             while (l2 < h2) {
@@ -739,28 +811,22 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                                 if (L.s_off[mid] <= e) l2 = mid;
                                 else h2 = mid - 1;
                             }
-                            ww[k] = L.s_node[l2];
-                            jj[k] = P.rowarc[L.s_p0[l2] + (e - L.s_off[l2])];
+                            const int p = L.s_p0[l2] + (e - L.s_off[l2]);
+                            jj[k] = P.rowarc[p];
+                            oo[k] = P.rowother[p];
+                            yw[k] = P.y[L.s_node[l2]];
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         st[k] = ST_TREE;
-                        tl[k] = hd[k] = 0;
-                        if (live[k]) {
-                            st[k] = P.state[jj[k]];
-                            tl[k] = P.tail[jj[k]];
-                            hd[k] = P.head[jj[k]];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < U; ++k) {
                         po[k] = 0;
-                        yt[k] = yh[k] = cs[k] = cp[k] = 0.0;
-                        if (st[k] != ST_TREE) {
-                            po[k] = nd[tl[k] == ww[k] ? hd[k] : tl[k]].z;
-                            yt[k] = P.y[tl[k]];
-                            yh[k] = P.y[hd[k]];
+                        yo[k] = cs[k] = cp[k] = 0.0;
+                        if (live[k]) {
+                            const int o = oo[k] < 0 ? ~oo[k] : oo[k];
+                            st[k] = P.state[jj[k]];
+                            po[k] = nd[o].z;
+                            yo[k] = P.y[o];
                             cs[k] = P.cost[jj[k]];
                             cp[k] = P.cap[jj[k]];
                         }
@@ -768,12 +834,11 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         bool elig = false;
-                        if (st[k] != ST_TREE && !in_S(po[k])) {
-                            const bool tail_in = tl[k] == ww[k];
+                        const bool tail_in = oo[k] >= 0; // this end (inside S) is the arc's tail
+                        if (st[k] != ST_TREE && !in_S(po[k]))
                             elig = tau > 0 ? (tail_in ? st[k] == ST_LOWER : st[k] == ST_UPPER)
                                            : (tail_in ? st[k] == ST_UPPER : st[k] == ST_LOWER);
-                        }
-                        const double rc = (cs[k] - yt[k]) + yh[k];
+                        const double rc = tail_in ? (cs[k] - yw[k]) + yo[k] : (cs[k] - yo[k]) + yw[k];
                         append_lds(elig, jj[k], fabs(rc), cp[k]);
                     }
                 }
@@ -1201,6 +1266,9 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_TRY(pool.get(V, &P.spos));
     SX_TRY(pool.get(V, &P.ssize));
     SX_TRY(pool.get(V, &P.pathidx));
+    SX_TRY(pool.get(2 * E, &P.rowother));
+    SX_TRY(pool.get(V, &P.noderec));
+    SX_TRY(pool.get(V, &P.ordrec));
     SX_HIP(hipMemsetAsync(P.pathidx, 0, sizeof(int32_t) * static_cast<size_t>(V), s));
     for (int k = 0; k < 2; ++k) {
         SX_TRY(pool.get(V > ND_GMAX ? V : ND_GMAX, &P.acc[k]));
@@ -1211,6 +1279,7 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_HIP(hipEventRecord(ev[0], s));
     // ---- set-up: tree, potentials, dual feasibility by flips, tree flows
     hipLaunchKernelGGL(k_nd_tree, dim3(1), dim3(ND_T), 0, s, P);
+    hipLaunchKernelGGL(k_nd_adjacency, dim3(static_cast<unsigned>((V * 64 + 255) / 256)), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_nd_flip, dim3(static_cast<unsigned>((E + 255) / 256)), dim3(256), 0, s, P, xn);
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
@@ -1219,6 +1288,7 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
         for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
         return SX_OK;
     }
+    hipLaunchKernelGGL(k_nd_ordrec, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P); // (order[] is valid now)
     SX_TRY(sx_score_rows_dev(ctx, A, xn, b, nullptr, 0.0, beff, nullptr)); // b - A x_N, sums in stored order
     hipLaunchKernelGGL(k_nd_excess, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, beff);
     hipLaunchKernelGGL(k_nd_initflows, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P);
