@@ -314,8 +314,12 @@ def main():
     # SX_BENCH_REHEARSAL=gloo: exercise the N > 1 code path on a box with ONE GPU -- every rank uses
     # device 0 and the two collectives go over gloo through CPU staging.  Numbers from it mean nothing.
     rehearse = world > 1 and os.environ.get("SX_BENCH_REHEARSAL") == "gloo"
+    # SX_BENCH_REHEARSAL=rccl1: ONE rank takes the N > 1 code path over RCCL itself (process group "nccl", the
+    # all-gather of the 48-byte records, barrier, MAX all-reduce of the time, the sharded CG's all-reduce) -- the
+    # rehearsal of the RCCL calls that a box with one GPU allows; launch it under torch.distributed.run as well
+    use_dist = world > 1 or os.environ.get("SX_BENCH_REHEARSAL") == "rccl1"
     dev_index = 0 if rehearse else local_rank
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -373,7 +377,7 @@ def main():
     s_p, flag = ctx.empty(m_loc, np.float64), ctx.empty(m_loc, np.uint8)
     idx_low, idx_up, idx_row = ctx.empty(n_loc, np.int64), ctx.empty(n_loc, np.int64), ctx.empty(m_loc, np.int64)
     vb = ctx.to_device(np.full(n_loc, -1, dtype=np.int8))
-    if world > 1:
+    if use_dist:
         # one 48-byte record per rank and step: pricing record (24 B) + the three set sizes (3 x int64),
         # exchanged by ONE all-gather; every rank reduces the gathered records itself
         t_rec = torch.zeros(48, dtype=torch.uint8, device="cuda")
@@ -410,7 +414,7 @@ def main():
         ctx.price(dC, d_y, d_c, vb, 1e-6, None, price)
         if timed:
             ctx.marker(5 * i + 4)
-        if world > 1 and not rehearse:
+        if use_dist and not rehearse:
             dist.all_gather_into_tensor(t_gather, t_rec)
         elif rehearse:
             cpu_gather = torch.empty(48 * world, dtype=torch.uint8)
@@ -418,7 +422,7 @@ def main():
             t_gather.copy_(cpu_gather)
 
     def fence():
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -434,7 +438,7 @@ def main():
         step(i, i < n_marked)
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -527,7 +531,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_loc / (elapsed / args.steps)
 
-    if world > 1:
+    if use_dist:
         from smart_crossover import distributed as D
         raw = t_gather.cpu().numpy().tobytes()
         recs = [D.unpack_price(raw[r * 48:r * 48 + 24]) for r in range(world)]
@@ -547,24 +551,24 @@ def main():
         xa = ops.vec(rng.uniform(0.1, 1.0, n_loc))
         xs = ops.vec(np.where(rng.random(m) < 0.5, rng.uniform(0.1, 1.0, m), 0.0))
         st = ops.cg_open(A_loc, xa, xs, ops.vec(sh.c), 1e-30)
-        if world > 1 and not rehearse:
+        if use_dist and not rehearse:
             dist.all_reduce(st["q"])
         ops.cg_start(st)
         for k in range(3):                                         # warm-up
             ops.cg_local(st)
-            if world > 1 and not rehearse:
+            if use_dist and not rehearse:
                 dist.all_reduce(st["q"])
             ops.cg_update(st, k)
         fence()
         t_cg = time.perf_counter()
         for k in range(args.cg_iters):
             ops.cg_local(st)
-            if world > 1 and not rehearse:
+            if use_dist and not rehearse:
                 dist.all_reduce(st["q"])
             ops.cg_update(st, k + 3)
         fence()
         cg_elapsed = time.perf_counter() - t_cg
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([cg_elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             cg_elapsed = float(tt.item())
@@ -644,7 +648,7 @@ def main():
             "device": dev_name,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -60,3 +60,26 @@ def test_sharded_lp_and_mcf_with_the_real_kernels(tmp_path):
                       {"SX_DIST_OPS": "hip", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LOCAL_RANK": "0"})
     assert res["world"] == 2
     check_sharded_results(res)
+
+
+def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
+    """``bench.py``'s N > 1 path over RCCL itself, as far as a box with one GPU allows: one rank under
+    torch.distributed.run with SX_BENCH_REHEARSAL=rccl1 -- process group "nccl" on the device, kernels and
+    collectives on one stream, the all-gather of the 48-byte records, barrier, MAX all-reduce of the time and the
+    sharded CG's m-vector all-reduce.  The step's result must be the single-process one."""
+    root = os.path.dirname(HERE)
+    common = ["--gpus", "1", "--workload", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-crossover",
+              "--no-uniform"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, env=env, capture_output=True,
+                           timeout=600, cwd=root)
+    assert plain.returncode == 0, plain.stderr.decode(errors="replace")[-2000:]
+    env["SX_BENCH_REHEARSAL"] = "rccl1"
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py")]
+                          + common + ["--cg-iters", "5"], env=env, capture_output=True, timeout=600, cwd=root)
+    assert dist.returncode == 0, dist.stderr.decode(errors="replace")[-2000:]
+    a = json.loads(plain.stdout.decode().strip().splitlines()[-1])
+    b = json.loads(dist.stdout.decode().strip().splitlines()[-1])
+    assert a["result"] == b["result"] and b["result"]["fix_low"] > 0
+    assert b["n_gpus"] == 1 and b["sharded_cg"]["iterations"] == 5
