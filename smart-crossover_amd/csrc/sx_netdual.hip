@@ -27,6 +27,7 @@
 
 #include <hip/hip_cooperative_groups.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -40,6 +41,9 @@ constexpr int ND_GMAX = 256;     // workgroups of the cooperative grid (one per 
 constexpr int ND_PATH_LDS = 1024; // path entries cached in LDS for the new positions
 constexpr int ND_SMALL = 512;     // subtrees up to this many nodes: workgroup 0 scans the cut alone
 constexpr int ND_LCAP = 2048;     // candidates of the ratio test kept in LDS
+#ifndef SX_ND_FINE_TICKS
+#define SX_ND_FINE_TICKS 0 // 1: SX_NS_PROFILE also splits the pass into loads / compute (costs a drain per round)
+#endif
 constexpr int ND_PUSH_LDS = 64;   // moved arcs of a decision cached in LDS for the pass
 constexpr int ST_TREE = 0, ST_LOWER = 1, ST_UPPER = -1;
 constexpr int UNK = -2;
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
 // the passes' plain stores visible across the XCDs' L2s, as the cooperative-groups barrier does.
 __device__ __forceinline__ void nd_barrier(unsigned long long *counter, unsigned long long &epoch, int G, int naps) {
     __syncthreads();
+    if (G == 1) return; // one workgroup: its own barrier orders everything, and the caches stay warm
     ++epoch;
     if (threadIdx.x == 0) {
         const unsigned long long target = epoch * static_cast<unsigned long long>(G);
@@ -518,6 +523,10 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     ck[k] = P.cap[rk[k].y];
                 }
             }
+            if (SX_ND_FINE_TICKS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tick(7);
+            }
             if (rb == 0 && (cached || pcached)) { // (first round only) the decision's lists -> LDS
                 __syncthreads();
                 if (cached)
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 }
             }
         }
+        if (SX_ND_FINE_TICKS) tick(5);
         nd_argmax(L, bs, bn);
         if (tid == 0) {
             P.part_s[g] = bs;
@@ -1296,7 +1306,10 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     int per_cu = 0;
     SX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_nd_solve, ND_T, 0));
     int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    int64_t want = (V + 2 * ND_T - 1) / (2 * ND_T); // two nodes per lane in the pass: fewer workgroups at the barriers pay for it
+    // one node per lane in the pass up to 64 workgroups, two beyond: more workgroups cost more at the two barriers
+    // (and their polling slows workgroup 0) than the second node costs in the pass (profiles/r02/netdual_grid_sweep.txt)
+    int64_t want = (V + ND_T - 1) / ND_T;
+    if (want > 64) want = std::max<int64_t>(64, (V + 2 * ND_T - 1) / (2 * ND_T));
     int G = static_cast<int>(want < 1 ? 1 : want);
     if (ctx->opt_nd_grid > 0) G = ctx->opt_nd_grid;
     if (G > ND_GMAX) G = ND_GMAX;
@@ -1328,11 +1341,11 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
     if (getenv("SX_NS_PROFILE"))
         fprintf(stderr, "[sx_netdual] V=%lld E=%lld grid=%d iterations=%lld flips=%lld status=%lld | set-up %.1f ms, solve %.1f ms | "
-                        "us per iteration: pass %.2f wide cut %.2f cut %.2f ratio %.2f publish %.2f (-) %.2f barriers %.2f | per iteration: "
+                        "us per iteration: pass %.2f wide cut %.2f cut %.2f ratio %.2f publish %.2f (pass compute %.2f) barriers %.2f (pass loads %.2f) | per iteration: "
                         "candidates %.1f, subtree %.1f (alone %.0f%%), path %.1f, positions moved %.1f\n",
                 (long long)V, (long long)E, G, sh.iters, sh.flips, sh.status, ms_setup, ms_solve,
                 sh.t_phase[0] * 0.01 / it_n, sh.t_phase[1] * 0.01 / it_n, sh.t_phase[2] * 0.01 / it_n, sh.t_phase[3] * 0.01 / it_n,
-                sh.t_phase[4] * 0.01 / it_n, sh.t_phase[5] * 0.01 / it_n, sh.t_phase[6] * 0.01 / it_n, sh.sum_cand / it_n,
+                sh.t_phase[4] * 0.01 / it_n, sh.t_phase[5] * 0.01 / it_n, sh.t_phase[6] * 0.01 / it_n, sh.t_phase[7] * 0.01 / it_n, sh.sum_cand / it_n,
                 sh.sum_sub / it_n, 100.0 * sh.n_small / it_n, sh.sum_path / it_n, sh.sum_range / it_n);
     result->status = sh.status;
     result->iters = sh.iters;
