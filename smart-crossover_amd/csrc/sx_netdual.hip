@@ -59,6 +59,7 @@ struct NdDec { // an iteration's decision: written by workgroup 0, applied by al
     int to_lower;   // the leaving arc lands on 0 (else on its capacity)
     int lo, hi, newstart; // preorder positions [lo, hi) change; S starts at newstart
     double dy;      // shift of the potentials of S
+    double enter_flow, enter_cap; // the entering arc: it hangs u_in from now on
 };
 
 struct NdShared {
@@ -85,10 +86,12 @@ struct NdProblem {
     const int32_t *rowarc;
     int32_t *rowother;     // per CSR entry: the arc's other end o, or ~o when this row is the arc's head
     int2 *noderec;         // per node: {first CSR entry, degree}
-    int2 *ordrec;          // the same by preorder position (kept with order[])
+    int4 *ordq;            // by preorder position: {node, first CSR entry, degree, -}: order[] of the iterations
     int32_t *tail, *head;
     const double *cost, *cap;
-    double *flow;
+    double *flow;          // [E] non-tree arcs' values (tree arcs: filled in at the end from nflow)
+    double *nflow, *ncap;  // [V] flow and capacity of the arc that hangs a node (coalesced in the pass)
+    double *sflow, *scap;  // [V] those of the path nodes before the re-hang
     int8_t *state;
     int4 *nd;       // {parent, pred arc, pos, size}
     double *y;
@@ -278,7 +281,11 @@ __global__ __launch_bounds__(256) void k_nd_adjacency(NdProblem P) {
 
 __global__ __launch_bounds__(256) void k_nd_ordrec(NdProblem P) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < P.V) P.ordrec[t] = P.noderec[P.order[t]];
+    if (t < P.V) {
+        const int w = P.order[t];
+        const int2 rec = P.noderec[w];
+        P.ordq[t] = make_int4(w, rec.x, rec.y, 0);
+    }
 }
 
 // dual feasibility by moving arcs to their other bound; x_N for the right-hand side
@@ -326,7 +333,11 @@ __global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= P.V) return;
     const int4 r = P.nd[w];
-    if (r.x < 0) return;
+    if (r.x < 0) {
+        P.nflow[w] = 0.0;
+        P.ncap[w] = INFINITY; // the root hangs on nothing
+        return;
+    }
     int t = r.z;
     const int end = r.z + r.w;
     double s = 0.0;
@@ -336,7 +347,8 @@ __global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
         t += 256;
     }
     while (t < end) s = s + P.e[t++];
-    P.flow[r.y] = (P.tail[r.y] == w) ? s : -s;
+    P.nflow[w] = (P.tail[r.y] == w) ? s : -s;
+    P.ncap[w] = P.cap[r.y];
 }
 
 // ------------------------------------------------------------------ grid barrier
@@ -505,23 +517,13 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             // decision is looked at, the flow and capacity of its arc right behind -- two levels of loads
             long long wk[2] = {base, base + gsize};
             int4 rk[2];
-            int pik[2];
-            int2 reck[2];
             double fk[2], ck[2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 2; ++k) { // three coalesced loads per node, no gathers
                 const long long w = wk[k] < V ? wk[k] : 0;
                 rk[k] = nd[w];
-                pik[k] = P.pathidx[w];
-                reck[k] = P.noderec[w];
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                fk[k] = ck[k] = 0.0;
-                if (rk[k].y >= 0) {
-                    fk[k] = P.flow[rk[k].y];
-                    ck[k] = P.cap[rk[k].y];
-                }
+                fk[k] = P.nflow[w];
+                ck[k] = P.ncap[w];
             }
             if (SX_ND_FINE_TICKS) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,24 +553,25 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 double f = fk[k], c = ck[k];
                 if (D.has) {
                     const bool inside = r.z >= D.a_pos && r.z < D.a_pos + D.n_sub;
-                    const int pi = inside ? pik[k] : 0; // 1 + index on the path u_in .. v
+                    const int pi = inside ? P.pathidx[w] : 0; // 1 + index on the path u_in .. v
                     if (w != root) {
                         // the arc that hangs w after the re-hang, and the subtree it closed before: a path node
                         // takes over the arc of the path node below it
                         int arc = r.y, iz = r.z, iw = r.w, owner = static_cast<int>(w);
-                        if (pi > 0) {
-                            if (pi == D.K) P.flow[r.y] = D.to_lower ? 0.0 : c; // the leaving arc lands on its bound
+                        bool changed = false;
+                        if (pi > 0) { // (the leaving arc, v's old one, got its bound from workgroup 0)
+                            changed = true;
                             if (pi == 1) {
-                                arc = -1; // the entering arc: workgroup 0 set its flow
-                                f = P.flow[D.enter];
-                                c = P.cap[D.enter];
+                                arc = -1; // the entering arc
+                                f = D.enter_flow;
+                                c = D.enter_cap;
                             } else {
                                 arc = P.sarc[pi - 2];
                                 iz = s_pos(pi - 2);
                                 iw = s_size(pi - 2);
                                 owner = P.snode[pi - 2];
-                                f = P.flow[arc];
-                                c = P.cap[arc];
+                                f = P.sflow[pi - 2];
+                                c = P.scap[pi - 2];
                             }
                         }
                         if (arc >= 0) {
@@ -585,8 +588,12 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                             }
                             if (any) {
                                 f = f + ((P.tail[arc] == owner) ? d : -d);
-                                P.flow[arc] = f;
+                                changed = true;
                             }
+                        }
+                        if (changed) {
+                            P.nflow[w] = f;
+                            if (pi > 0) P.ncap[w] = c;
                         }
                     }
                     int4 q = r;
@@ -625,8 +632,8 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                             nt = D.b_pos < D.a_pos ? t + D.n_sub : t - D.n_sub;
                         }
                         q.z = nt;
-                        P.order[nt] = static_cast<int>(w);
-                        P.ordrec[nt] = reck[k];
+                        const int2 rec = P.noderec[w];
+                        P.ordq[nt] = make_int4(static_cast<int>(w), rec.x, rec.y, 0);
                     }
                     if (q.x != r.x || q.y != r.y || q.z != r.z || q.w != r.w) nd[w] = q;
                     r = q;
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         const int v = bn;
         const int4 rv = nd[v];
         const int a = rv.y, a_pos = rv.z, n_sub = rv.w;
-        const double f_a = P.flow[a], cap_a = P.cap[a];
+        const double f_a = P.nflow[v], cap_a = P.ncap[v];
         const bool to_lower = -f_a >= f_a - cap_a;
         const double delta = to_lower ? -f_a : f_a - cap_a;
         const bool a_out = P.tail[a] == v;
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         if (!small) { // a large subtree: all workgroups scan
             if (static_cast<long long>(n_sub) * 4 <= V) { // the adjacency of S's nodes, one wave per node
                 for (int t = a_pos + gwave; t < a_pos + n_sub; t += nwaves) {
-                    const int w = P.order[t];
+                    const int w = P.ordq[t].x;
                     const int64_t p0 = P.rowptr[w], p1 = P.rowptr[w + 1];
                     for (int64_t p = p0; p < p1; p += 64) { // uniform trip count: the slots come from wave ballots
                         const int64_t q = p + lane;
@@ -756,10 +763,10 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 // [off[t], off[t + 1]) of the flattened list (n_sub <= ND_SMALL <= ND_T: one node per lane)
                 int w = -1, p0 = 0, deg = 0;
                 if (tid < n_sub) {
-                    w = P.order[a_pos + tid];
-                    const int2 rec = P.ordrec[a_pos + tid];
-                    p0 = rec.x;
-                    deg = rec.y;
+                    const int4 rec = P.ordq[a_pos + tid];
+                    w = rec.x;
+                    p0 = rec.y;
+                    deg = rec.z;
                 }
                 int incl = deg;
 #pragma unroll
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     const int t = t0 + tid;
                     bool on = false;
                     if (t < n_sub) {
-                        const int w = small ? L.s_node[t] : P.order[a_pos + t];
+                        const int w = small ? L.s_node[t] : P.ordq[a_pos + t].x;
                         const int4 r = nd[w];
                         on = r.z <= p_uin && p_uin < r.z + r.w;
                     }
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     int w = 0;
                     int4 r = make_int4(0, 0, 0, 0);
                     if (t < n_sub) {
-                        w = small ? L.s_node[t] : P.order[a_pos + t];
+                        w = small ? L.s_node[t] : P.ordq[a_pos + t].x;
                         r = nd[w];
                         on = r.z <= p_uin && p_uin < r.z + r.w;
                     }
@@ -1054,6 +1061,8 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                         P.sarc[i] = r.y;
                         P.spos[i] = r.z;
                         P.ssize[i] = r.w;
+                        P.sflow[i] = P.nflow[w];
+                        P.scap[i] = P.ncap[w];
                         P.pathidx[w] = i + 1;
                     }
                     before += total;
@@ -1069,11 +1078,13 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     P.push_ph[i] = nd[P.head[j]].z;
                     P.push_d[i] = st == ST_LOWER ? c : -c;
                 }
+                double enter_flow = 0.0;
                 if (tid == 0) {
                     const int st = P.state[enter];
                     const double d = st == ST_LOWER ? remaining : -remaining;
-                    P.flow[enter] = (st == ST_LOWER ? 0.0 : cap_e) + d;
+                    enter_flow = (st == ST_LOWER ? 0.0 : cap_e) + d;
                     P.state[enter] = ST_TREE;
+                    P.flow[a] = to_lower ? 0.0 : cap_a; // the leaving arc lands exactly on its bound
                     P.push_pt[npush] = pt;
                     P.push_ph[npush] = ph;
                     P.push_d[npush] = d;
@@ -1087,6 +1098,8 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 N.n_sub = n_sub;
                 N.to_lower = to_lower ? 1 : 0;
                 N.dy = tau > 0 ? theta : -theta;
+                N.enter_flow = enter_flow; // (lane 0's value is the one that is stored)
+                N.enter_cap = cap_e;
                 N.lo = a_pos < b_pos + 1 ? a_pos : b_pos + 1;
                 N.hi = a_pos + n_sub > b_pos + 1 ? a_pos + n_sub : b_pos + 1;
                 N.newstart = b_pos < a_pos ? b_pos + 1 : b_pos + 1 - n_sub;
@@ -1137,7 +1150,12 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         nd_barrier(P.bar, epoch, G, P.nap_short); // part_cnt is rewritten in the next round
         if (!any) break;
     }
-    for (long long w = gtid; w < V; w += gsize) P.y[w] = P.acc[cur][w];
+    for (long long w = gtid; w < V; w += gsize) {
+        P.y[w] = P.acc[cur][w];
+        const int4 r = nd[w];
+        if (r.x >= 0) P.flow[r.y] = P.nflow[w]; // the tree arcs' flows were kept by node
+    }
+    nd_barrier(P.bar, epoch, G, P.nap_short);
     // objective and largest bound violation: fixed order (lane-strided partials, workgroup order)
     double part = 0.0, worst = 0.0;
     for (long long e = gtid; e < E; e += gsize) {
@@ -1278,7 +1296,11 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_TRY(pool.get(V, &P.pathidx));
     SX_TRY(pool.get(2 * E, &P.rowother));
     SX_TRY(pool.get(V, &P.noderec));
-    SX_TRY(pool.get(V, &P.ordrec));
+    SX_TRY(pool.get(V, &P.ordq));
+    SX_TRY(pool.get(V, &P.nflow));
+    SX_TRY(pool.get(V, &P.ncap));
+    SX_TRY(pool.get(V, &P.sflow));
+    SX_TRY(pool.get(V, &P.scap));
     SX_HIP(hipMemsetAsync(P.pathidx, 0, sizeof(int32_t) * static_cast<size_t>(V), s));
     for (int k = 0; k < 2; ++k) {
         SX_TRY(pool.get(V > ND_GMAX ? V : ND_GMAX, &P.acc[k]));
