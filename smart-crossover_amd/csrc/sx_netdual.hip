@@ -70,6 +70,8 @@ struct NdShared {
     double max_violation;
     int not_network;
     int ntree, nroot, root;
+    int any_capacity; // a non-tree arc with a finite capacity exists
+    int any_nontree;
     int cand_count;
     int pad_;
     NdDec dec;
@@ -148,6 +150,10 @@ __global__ __launch_bounds__(256) void k_nd_endpoints(int64_t E, const int64_t *
     state[j] = static_cast<int8_t>(st);
     if (!ok) sh->not_network = 1;
     if (st == ST_TREE) atomicAdd(&sh->ntree, 1);
+    else {
+        sh->any_nontree = 1; // benign races: every writer stores 1
+        if (!isinf(u[j])) sh->any_capacity = 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nd_root(int64_t V, const int8_t *__restrict__ cbasis, NdShared *sh) {
@@ -1269,6 +1275,9 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
     if (sh.not_network || sh.ntree != V - 1 || sh.nroot != 1) return SX_OK;
+    // no capacitated arc outside the tree (the OT crossovers): nothing can be flipped, the start is dual feasible
+    // only if it is optimal already -- the primal method's case, decided here before any set-up work
+    if (sh.any_nontree && !sh.any_capacity && ctx->opt_netdual < 1) return SX_OK;
     if (x_out) P.flow = x_out;
     else SX_TRY(pool.get(E, &P.flow));
     if (y_out) P.y = y_out;

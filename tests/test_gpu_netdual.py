@@ -181,3 +181,36 @@ def test_non_integral_data_reach_the_optimum(ctx):
     want = dual_network_simplex(tail, head, c, u, b, vb, root=V)
     assert abs(int(res.iters) - want["iters"]) <= max(5, want["iters"] // 20)
     assert float(res.obj) == pytest.approx(want["obj"], rel=1e-9)
+
+
+def test_iteration_limit_and_tiny_networks(ctx):
+    # the limit stops the run with status 3 and a consistent state: a spanning tree, flows that conserve
+    A, b, c, u, tail, head, vb, cb = big_m_network(300, 3000, 2, inf_frac=0.0)
+    res, x, y, vbo, cbo = run(ctx, A, b, c, u, vb, cb, max_iter=25)
+    assert int(res.status) == 3 and int(res.iters) == 25
+    assert np.count_nonzero(vbo == 0) == A.shape[0] - 1
+    assert np.abs(A @ x - b).max() <= 1e-9 * (1 + np.abs(b).max())
+    # ... and continuing from that basis reaches the optimum of the uninterrupted run
+    full = run(ctx, A, b, c, u, vb, cb)
+    res2, x2, y2, vb2, cb2 = run(ctx, A, b, c, u, vbo.astype(np.int8), cbo.astype(np.int8))
+    assert int(res2.status) == 0 and float(res2.obj) == pytest.approx(float(full[0].obj), rel=1e-12)
+    # two nodes, one arc + the root's artificial arcs
+    for V, E, seed in ((2, 1, 0), (3, 2, 1), (5, 4, 3)):
+        A, b, c, u, tail, head, vb, cb = big_m_network(V, E, seed, inf_frac=0.0)
+        res, x, y, vbo, cbo = run(ctx, A, b, c, u, vb, cb)
+        want = dual_network_simplex(tail, head, c, u, b, vb, root=V)
+        same_pivots(res, x, vbo, want)
+        assert float(res.obj) == pytest.approx(highs(A, b, c, u), rel=1e-9, abs=1e-9)
+
+
+def test_uncapacitated_networks_go_to_the_primal_method_at_once(ctx):
+    """No capacitated arc outside the tree (the OT crossovers): the dual method declines before any set-up work,
+    unless it is forced -- and forced it still answers correctly (optimal start) or declines (an arc would have to
+    flip)."""
+    A, b, c, u, tail, head, vb, cb = big_m_network(60, 400, 1, inf_frac=1.0)
+    assert int(run(ctx, A, b, c, u, vb, cb)[0].status) == 5
+    ctx.set_option("netdual", 1)
+    try:
+        assert int(run(ctx, A, b, c, u, vb, cb)[0].status) == 5       # wrong-signed uncapacitated arcs
+    finally:
+        ctx.set_option("netdual", -1)
