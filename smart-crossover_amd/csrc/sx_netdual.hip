@@ -115,6 +115,7 @@ struct NdProblem {
     NdShared *sh;
     unsigned long long *bar; // grid barrier: arrivals
     int nap_short, nap_long; // naps between polls: after a pass / while workgroup 0 decides
+    int lazy;                // 1: barriers without cache invalidation where the next phase allows it (nd_barrier)
 };
 
 // ------------------------------------------------------------------ arcs from the columns of A
@@ -362,18 +363,39 @@ __global__ __launch_bounds__(256) void k_nd_initflows(NdProblem P) {
 // with naps in between: while workgroup 0 decides alone, 128 workgroups polling the same line without a pause
 // slow its dependent loads by a factor of two (profiles/r02/netdual.md).  Release / acquire at agent scope make
 // the passes' plain stores visible across the XCDs' L2s, as the cooperative-groups barrier does.
-__device__ __forceinline__ void nd_barrier(unsigned long long *counter, unsigned long long &epoch, int G, int naps) {
+// `acquire` = false: the workgroup goes on WITHOUT invalidating its caches.  An acquire at agent scope empties the
+// CU's L1 and the XCD's L2 of everything that is not dirty, and then every load of the next phase misses; a
+// workgroup whose next phase reads only (a) data it wrote itself -- the pass: every node's records belong to one
+// lane for the whole solve -- and (b) a handful of values written elsewhere, which it fetches with nd_ld() (loads
+// at agent scope, served from memory), does not need that.  The release (arrivals) is always there.
+__device__ __forceinline__ void nd_barrier(unsigned long long *counter, unsigned long long &epoch, int G, int naps,
+                                           bool acquire = true) {
     __syncthreads();
     if (G == 1) return; // one workgroup: its own barrier orders everything, and the caches stay warm
     ++epoch;
     if (threadIdx.x == 0) {
         const unsigned long long target = epoch * static_cast<unsigned long long>(G);
         __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks
+        if (acquire) {
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+                for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16); // 16 x 64 clocks
+        } else {
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+                for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16);
         }
     }
     __syncthreads();
+}
+
+// a value another workgroup wrote before the last barrier, read without an acquire of this workgroup's own
+template <class T>
+__device__ __forceinline__ T nd_ld(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int4 nd_ld4(const int4 *p) {
+    const long long *q = reinterpret_cast<const long long *>(p);
+    const long long a = nd_ld(q), b = nd_ld(q + 1);
+    return make_int4(static_cast<int>(a), static_cast<int>(a >> 32), static_cast<int>(b), static_cast<int>(b >> 32));
 }
 
 // ------------------------------------------------------------------ workgroup reductions
@@ -508,7 +530,25 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
 
     while (true) {
         // ================================================== pass: apply the decision, score the tree arcs
-        const NdDec D = sh->dec;
+        NdDec D;
+        {
+            const NdDec *d = &sh->dec;
+            D.has = nd_ld(&d->has);
+            D.enter = nd_ld(&d->enter);
+            D.v_in = nd_ld(&d->v_in);
+            D.b_pos = nd_ld(&d->b_pos);
+            D.a_pos = nd_ld(&d->a_pos);
+            D.n_sub = nd_ld(&d->n_sub);
+            D.K = nd_ld(&d->K);
+            D.npush = nd_ld(&d->npush);
+            D.to_lower = nd_ld(&d->to_lower);
+            D.lo = nd_ld(&d->lo);
+            D.hi = nd_ld(&d->hi);
+            D.newstart = nd_ld(&d->newstart);
+            D.dy = nd_ld(&d->dy);
+            D.enter_flow = nd_ld(&d->enter_flow);
+            D.enter_cap = nd_ld(&d->enter_cap);
+        }
         if (D.has && D.enter < 0) {
             status = 1;
             break;
@@ -539,18 +579,18 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 __syncthreads();
                 if (cached)
                     for (int i = tid; i < D.K; i += ND_T) {
-                        L.spos[i] = P.spos[i];
-                        L.ssize[i] = P.ssize[i];
+                        L.spos[i] = nd_ld(&P.spos[i]);
+                        L.ssize[i] = nd_ld(&P.ssize[i]);
                     }
                 if (pcached && tid < D.npush) {
-                    L.p_pt[tid] = P.push_pt[tid];
-                    L.p_ph[tid] = P.push_ph[tid];
-                    L.p_d[tid] = P.push_d[tid];
+                    L.p_pt[tid] = nd_ld(&P.push_pt[tid]);
+                    L.p_ph[tid] = nd_ld(&P.push_ph[tid]);
+                    L.p_d[tid] = nd_ld(&P.push_d[tid]);
                 }
                 __syncthreads();
             }
-            auto s_pos = [&](int i) { return cached ? L.spos[i] : P.spos[i]; };
-            auto s_size = [&](int i) { return cached ? L.ssize[i] : P.ssize[i]; };
+            auto s_pos = [&](int i) { return cached ? L.spos[i] : nd_ld(&P.spos[i]); };
+            auto s_size = [&](int i) { return cached ? L.ssize[i] : nd_ld(&P.ssize[i]); };
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const long long w = wk[k];
@@ -559,7 +599,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                 double f = fk[k], c = ck[k];
                 if (D.has) {
                     const bool inside = r.z >= D.a_pos && r.z < D.a_pos + D.n_sub;
-                    const int pi = inside ? P.pathidx[w] : 0; // 1 + index on the path u_in .. v
+                    const int pi = inside ? nd_ld(&P.pathidx[w]) : 0; // 1 + index on the path u_in .. v
                     if (w != root) {
                         // the arc that hangs w after the re-hang, and the subtree it closed before: a path node
                         // takes over the arc of the path node below it
@@ -572,22 +612,22 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                                 f = D.enter_flow;
                                 c = D.enter_cap;
                             } else {
-                                arc = P.sarc[pi - 2];
+                                arc = nd_ld(&P.sarc[pi - 2]);
                                 iz = s_pos(pi - 2);
                                 iw = s_size(pi - 2);
-                                owner = P.snode[pi - 2];
-                                f = P.sflow[pi - 2];
-                                c = P.scap[pi - 2];
+                                owner = nd_ld(&P.snode[pi - 2]);
+                                f = nd_ld(&P.sflow[pi - 2]);
+                                c = nd_ld(&P.scap[pi - 2]);
                             }
                         }
                         if (arc >= 0) {
                             double d = 0.0;
                             bool any = false;
                             for (int i = 0; i < D.npush; ++i) { // the subtree separates the ends of a moved arc
-                                const int pt = pcached ? L.p_pt[i] : P.push_pt[i], ph = pcached ? L.p_ph[i] : P.push_ph[i];
+                                const int pt = pcached ? L.p_pt[i] : nd_ld(&P.push_pt[i]), ph = pcached ? L.p_ph[i] : nd_ld(&P.push_ph[i]);
                                 const bool ti = pt >= iz && pt < iz + iw, hi = ph >= iz && ph < iz + iw;
                                 if (ti != hi) {
-                                    const double x = pcached ? L.p_d[i] : P.push_d[i];
+                                    const double x = pcached ? L.p_d[i] : nd_ld(&P.push_d[i]);
                                     d = d + (hi ? x : -x);
                                     any = true;
                                 }
@@ -604,8 +644,8 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
                     }
                     int4 q = r;
                     if (pi > 0) {
-                        q.x = pi == 1 ? D.v_in : P.snode[pi - 2];
-                        q.y = pi == 1 ? D.enter : P.sarc[pi - 2];
+                        q.x = pi == 1 ? D.v_in : nd_ld(&P.snode[pi - 2]);
+                        q.y = pi == 1 ? D.enter : nd_ld(&P.sarc[pi - 2]);
                         q.w = pi == 1 ? D.n_sub : D.n_sub - s_size(pi - 2);
                     } else if (!inside) {
                         const bool anc_v = r.z <= D.a_pos && D.a_pos < r.z + r.w;
@@ -665,13 +705,13 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             if (g == 0) sh->cand_count = 0;
         }
         tick(0);
-        nd_barrier(P.bar, epoch, G, P.nap_short); // ---- B1
+        nd_barrier(P.bar, epoch, G, P.nap_short, g == 0 || !P.lazy); // ---- B1: workgroup 0 reads everybody's pass
         tick(6);
         bs = 0.0;
         bn = 0x7fffffff;
         if (tid < G) {
-            bs = P.part_s[tid];
-            bn = P.part_n[tid];
+            bs = nd_ld(&P.part_s[tid]);
+            bn = nd_ld(&P.part_n[tid]);
         }
         nd_argmax(L, bs, bn);
         if (!(bs > 0.0)) {
@@ -684,9 +724,9 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
         }
         ++iters;
         const int v = bn;
-        const int4 rv = nd[v];
+        const int4 rv = nd_ld4(&nd[v]);
         const int a = rv.y, a_pos = rv.z, n_sub = rv.w;
-        const double f_a = P.nflow[v], cap_a = P.ncap[v];
+        const double f_a = nd_ld(&P.nflow[v]), cap_a = nd_ld(&P.ncap[v]);
         const bool to_lower = -f_a >= f_a - cap_a;
         const double delta = to_lower ? -f_a : f_a - cap_a;
         const bool a_out = P.tail[a] == v;
@@ -719,6 +759,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             }
         };
         if (!small) { // a large subtree: all workgroups scan
+            if (P.lazy && g != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // they read everybody's pass too
             if (static_cast<long long>(n_sub) * 4 <= V) { // the adjacency of S's nodes, one wave per node
                 for (int t = a_pos + gwave; t < a_pos + n_sub; t += nwaves) {
                     const int w = P.ordq[t].x;
@@ -1118,7 +1159,7 @@ __global__ __launch_bounds__(ND_T) void k_nd_solve(NdProblem P, long long max_it
             if (tid == 0) sh->dec = N;
             tick(4);
         }
-        nd_barrier(P.bar, epoch, G, P.nap_long); // ---- B3
+        nd_barrier(P.bar, epoch, G, P.nap_long, !P.lazy); // ---- B3: the pass reads its own nodes + nd_ld()
         tick(6);
     }
 
@@ -1353,6 +1394,8 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
         static const char *e1 = getenv("SX_ND_NAP_SHORT"), *e2 = getenv("SX_ND_NAP_LONG"); // experiments
         P.nap_short = e1 ? atoi(e1) : 0;
         P.nap_long = e2 ? atoi(e2) : 2;
+        static const char *e3 = getenv("SX_ND_LAZY");
+        P.lazy = e3 ? atoi(e3) : 1;
     }
     long long limit = max_iter > 0 ? max_iter : 100 * (V + E);
     void *args[] = {&P, &limit, &feas_tol};
