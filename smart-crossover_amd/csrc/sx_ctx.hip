@@ -67,6 +67,9 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
+    if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
+    if (ctx->nd_order) (void)hipFree(ctx->nd_order);
+    if (ctx->nd_y) (void)hipFree(ctx->nd_y);
     if (ctx->t_made)
         for (int i = 0; i < 8; ++i) {
             (void)hipEventDestroy(ctx->t0[i]);

@@ -58,6 +58,13 @@ struct sx_ctx {
     // row count takes it over instead of allocating (a crossover opens one session per call)
     double *spare_binv = nullptr;
     int64_t spare_binv_m = 0;
+    // tree arrays of the last dual network simplex solve (sx_netdual.hip): the next round of a column generation
+    // starts from that very tree, so its preorder, sizes and potentials need not be rebuilt
+    void *nd_tree = nullptr;      // int4[V] {parent, pred arc, pos, size}
+    int32_t *nd_order = nullptr;  // [V] node at preorder position
+    double *nd_y = nullptr;       // [V] potentials
+    int64_t nd_tree_V = 0;
+    int nd_tree_root = -1;
     // timers
     hipEvent_t t0[8];
     hipEvent_t t1[8];

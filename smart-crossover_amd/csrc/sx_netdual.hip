@@ -295,6 +295,30 @@ __global__ __launch_bounds__(256) void k_nd_ordrec(NdProblem P) {
     }
 }
 
+// the tree arrays kept from the previous solve describe THIS basis iff every node's arc is coded basic and joins it to
+// its parent (V - 1 distinct tree arcs out of the V - 1 the basis has)
+__global__ __launch_bounds__(256) void k_nd_check_kept(NdProblem P, int *__restrict__ differs) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= P.V) return;
+    const int4 r = P.nd[w];
+    bool ok;
+    if (r.x < 0) {
+        ok = w == P.sh->root;
+    } else {
+        ok = r.y >= 0 && r.y < P.E && r.x < P.V && P.state[r.y] == ST_TREE;
+        if (ok) {
+            const int t = P.tail[r.y], h = P.head[r.y];
+            ok = (t == w && h == r.x) || (h == w && t == r.x);
+        }
+    }
+    if (!ok) *differs = 1;
+}
+
+__global__ __launch_bounds__(256) void k_nd_keep_order(NdProblem P) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < P.V) P.order[t] = P.ordq[t].x;
+}
+
 // dual feasibility by moving arcs to their other bound; x_N for the right-hand side
 __global__ __launch_bounds__(256) void k_nd_flip(NdProblem P, double *__restrict__ xn) {
     const long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -1323,8 +1347,22 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     else SX_TRY(pool.get(E, &P.flow));
     if (y_out) P.y = y_out;
     else SX_TRY(pool.get(V, &P.y));
-    SX_TRY(pool.get(V, &P.nd));
-    SX_TRY(pool.get(V, &P.order));
+    // tree arrays live in the context: kept from solve to solve (a column generation's next round starts from the
+    // tree this one ends with)
+    bool kept = ctx->nd_tree && ctx->nd_tree_V == V && ctx->nd_tree_root == sh.root;
+    if (!kept) {
+        if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
+        if (ctx->nd_order) (void)hipFree(ctx->nd_order);
+        if (ctx->nd_y) (void)hipFree(ctx->nd_y);
+        ctx->nd_tree = ctx->nd_order = nullptr;
+        ctx->nd_y = nullptr;
+        ctx->nd_tree_V = 0;
+        SX_HIP(hipMalloc(&ctx->nd_tree, sizeof(int4) * static_cast<size_t>(V)));
+        SX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->nd_order), sizeof(int32_t) * static_cast<size_t>(V)));
+        SX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->nd_y), sizeof(double) * static_cast<size_t>(V)));
+    }
+    P.nd = static_cast<int4 *>(ctx->nd_tree);
+    P.order = ctx->nd_order;
     SX_TRY(pool.get(V > E ? V : E, &P.tmp)); // preorder move (V) and passed arcs of the ratio test (E)
     SX_TRY(pool.get(V, &P.first_child));
     SX_TRY(pool.get(V, &P.next_sib));
@@ -1360,7 +1398,19 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     for (int k = 0; k < 3; ++k) SX_HIP(hipEventCreate(&ev[k]));
     SX_HIP(hipEventRecord(ev[0], s));
     // ---- set-up: tree, potentials, dual feasibility by flips, tree flows
-    hipLaunchKernelGGL(k_nd_tree, dim3(1), dim3(ND_T), 0, s, P);
+    if (kept) { // is it this basis?
+        int *d_differs;
+        SX_TRY(pool.get(1, &d_differs));
+        SX_HIP(hipMemsetAsync(d_differs, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_nd_check_kept, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, d_differs);
+        int differs = 0;
+        SX_HIP(hipMemcpyAsync(&differs, d_differs, sizeof(int), hipMemcpyDeviceToHost, s));
+        SX_HIP(hipStreamSynchronize(s));
+        kept = !differs;
+    }
+    ctx->nd_tree_V = 0; // (valid again once this solve has run)
+    if (kept) SX_HIP(hipMemcpyAsync(P.y, ctx->nd_y, sizeof(double) * static_cast<size_t>(V), hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL(k_nd_tree, dim3(1), dim3(ND_T), 0, s, P);
     hipLaunchKernelGGL(k_nd_adjacency, dim3(static_cast<unsigned>((V * 64 + 255) / 256)), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_nd_flip, dim3(static_cast<unsigned>((E + 255) / 256)), dim3(256), 0, s, P, xn);
     SX_HIP(hipGetLastError());
@@ -1403,6 +1453,8 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_nd_solve), dim3(static_cast<unsigned>(G)), dim3(ND_T),
                                       args, 0, s));
     SX_HIP(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(k_nd_keep_order, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P);
+    SX_HIP(hipMemcpyAsync(ctx->nd_y, P.y, sizeof(double) * static_cast<size_t>(V), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_nd_outputs, dim3(static_cast<unsigned>(((E > V ? E : V) + 255) / 256)), dim3(256), 0, s, V, E,
                        P.state, sh.root, vbasis_out, cbasis_out);
     SX_HIP(hipGetLastError());
@@ -1421,10 +1473,14 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
                 sh.t_phase[0] * 0.01 / it_n, sh.t_phase[1] * 0.01 / it_n, sh.t_phase[2] * 0.01 / it_n, sh.t_phase[3] * 0.01 / it_n,
                 sh.t_phase[4] * 0.01 / it_n, sh.t_phase[5] * 0.01 / it_n, sh.t_phase[6] * 0.01 / it_n, sh.t_phase[7] * 0.01 / it_n, sh.sum_cand / it_n,
                 sh.sum_sub / it_n, 100.0 * sh.n_small / it_n, sh.sum_path / it_n, sh.sum_range / it_n);
+    if (sh.status == 0 || sh.status == 1 || sh.status == 3) { // the arrays describe the tree handed back
+        ctx->nd_tree_V = V;
+        ctx->nd_tree_root = sh.root;
+    }
     result->status = sh.status;
     result->iters = sh.iters;
-    result->phase1_iters = sh.flips; // arcs moved bound to bound (at the start and by the ratio test)
-    result->warm_start_used = 1;
+    result->phase1_iters = sh.flips;        // arcs moved bound to bound (at the start and by the ratio test)
+    result->warm_start_used = kept ? 2 : 1; // 2: the tree arrays of the previous solve were reused
     result->obj = sh.obj;
     result->max_violation = sh.max_violation;
     return SX_OK;

@@ -59,6 +59,7 @@ def test_from_the_artificial_star_pivot_for_pivot_with_the_oracle(ctx, V, E, see
     # the optimal basis handed back is a fixed point
     res2, x2, y2, vb2, cb2 = run(ctx, A, b, c, u, vbo.astype(np.int8), cbo.astype(np.int8))
     assert int(res2.status) == 0 and int(res2.iters) == 0 and int(res2.phase1_iters) == 0
+    assert int(res2.warm_start_used) == 2         # ... and the tree arrays kept from the first solve were reused
     assert np.array_equal(x2, x)
     np.testing.assert_array_equal(vb2, vbo)
 
@@ -80,6 +81,7 @@ def test_column_generation_round_new_arcs_at_either_bound(ctx):
     res, x, y, vbo, cbo = run(ctx, A, b, c, u, vb2, cb)
     want = dual_network_simplex(tail, head, c, u, b, vb2, root=V)
     same_pivots(res, x, vbo, want)
+    assert int(res.warm_start_used) == 1          # (the arcs are numbered differently here: kept tree arrays do not apply)
     assert int(res.phase1_iters) > 0                        # arcs were moved bound to bound
     certificates(A, b, c, u, tail, head, x, y, vbo, cbo)
     assert float(res.obj) == pytest.approx(highs(A, b, c, u), rel=1e-9, abs=1e-9)
