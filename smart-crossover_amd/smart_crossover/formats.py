@@ -159,10 +159,17 @@ class OptTransport:
         """(S+D) x (S*D) node-arc matrix: arc (i, j) = column i*D + j leaves supplier row i with -1
         and enters demander row S + j with +1."""
         S, D = self.s.size, self.d.size
-        arc = np.arange(S * D)
-        rows = np.concatenate([arc // D, S + arc % D])
+        # the CSR arrays written down directly (canonical: sorted columns, no duplicates): supplier row i holds the
+        # columns i*D .. i*D + D - 1, demander row S + j the columns j, j + D, j + 2D, ...
+        it = np.int32 if 2 * S * D < 2 ** 31 else np.int64   # one index type: scipy would convert otherwise
+        indptr = np.concatenate([np.arange(S + 1, dtype=it) * D, S * D + np.arange(1, D + 1, dtype=it) * S])
+        indices = np.concatenate([np.arange(S * D, dtype=it),
+                                  (np.arange(D, dtype=it)[:, None] + np.arange(S, dtype=it)[None, :] * D).ravel()])
         vals = np.concatenate([-np.ones(S * D), np.ones(S * D)])
-        return sp.csr_matrix((vals, (rows, np.concatenate([arc, arc]))), shape=(S + D, S * D))
+        A = sp.csr_matrix((vals, indices, indptr), shape=(S + D, S * D))
+        A.has_sorted_indices = True
+        A.has_canonical_format = True
+        return A
 
     def to_MCF(self) -> MinCostFlow:
         n = self.s.size * self.d.size
