@@ -422,7 +422,8 @@ int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const do
  * round's optimal tree plus new arcs at a bound (network_methods/algorithms.py:109-140).  Then: dual simplex on
  * the tree in preorder arrays, leaving arc by exact dual steepest edge (violation^2 / subtree size), bound-flipping
  * ratio test over the arcs of the cut, a cooperative grid of workgroups sharing every pass.  result->status:
- * 0 optimal, 1 primal infeasible, 3 iteration limit, 5 outside the domain (nothing solved: take
+ * 0 optimal, 1 primal infeasible, 3 iteration limit (max_iter, or 4 m + n / 2 + 100000 when max_iter <= 0), 5 outside
+ * the domain (nothing solved: take
  * sx_netsimplex_dev / sx_simplex_solve_dev); result->phase1_iters counts the arcs moved bound to bound;
  * result->warm_start_used = 2 when the tree arrays the context kept from its previous solve describe this basis
  * (a column generation's next round: same nodes, same arc numbers, more arcs) and the tree set-up was skipped.

@@ -187,7 +187,7 @@ class HipCaller(SolverCaller):
             # domain (an uncapacitated arc would have to flip, A is no incidence matrix, not a tree).  Then the
             # primal network simplex (K16n: needs a primal feasible tree); status 5 again: general simplex below
             res = ctx.net_dual(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, NETDUAL_FEAS_TOL, d_x, d_y, d_vb, d_cb)
-            if int(res.status) != 5:
+            if int(res.status) in (0, 1):       # (3 = its iteration limit: the primal method takes over from vb_in)
                 self._res, self.solved_by = res, "netdual"
             else:
                 res = ctx.net_simplex(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol),
