@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""CNET_MCF on the CPU with the oracle's dual network simplex (oracle/net_simplex.py) for the re-solves:
+"""(test infrastructure: uses oracle/) CNET_MCF on the CPU with the oracle's dual network simplex (oracle/net_simplex.py) for the re-solves:
 iterations per column-generation round, next to HiGHS' and the device primal method's (profiles/r02/network_simplex_ab.jsonl).
-usage: net_dual_proto.py V E [--no-bfrt] [--no-steepest]"""
+usage: tests/perf/net_dual_proto.py V E [--no-bfrt] [--no-steepest]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import workloads  # noqa: E402
 from oracle import net_path as N  # noqa: E402
