@@ -66,6 +66,7 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->ws3) (void)hipFree(ctx->ws3);
     if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
     if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
     if (ctx->nd_order) (void)hipFree(ctx->nd_order);
@@ -171,6 +172,7 @@ int sx_reserve(sx_ctx *ctx, size_t bytes) { return reserve_block(ctx, &ctx->ws, 
 // second grow-only block for kernels that call helpers using the first one (the radix sort keeps its
 // double buffers here while sx_scan_exclusive works in ctx->ws)
 int sx_reserve2(sx_ctx *ctx, size_t bytes) { return reserve_block(ctx, &ctx->ws2, &ctx->ws2_bytes, bytes); }
+int sx_reserve3(sx_ctx *ctx, size_t bytes) { return reserve_block(ctx, &ctx->ws3, &ctx->ws3_bytes, bytes); }
 
 SX_API int sx_malloc(sx_ctx *ctx, size_t bytes, void **dev_out) {
     SX_ENTER(ctx);

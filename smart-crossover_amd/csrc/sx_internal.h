@@ -54,6 +54,8 @@ struct sx_ctx {
     size_t ws_bytes = 0;
     void *ws2 = nullptr; // second block (sx_reserve2)
     size_t ws2_bytes = 0;
+    void *ws3 = nullptr; // third block (sx_reserve3): the temporaries of the network solvers, carved by sx_arena
+    size_t ws3_bytes = 0;
     // dense basis inverse of the last simplex session that was destroyed: the next session with the same
     // row count takes it over instead of allocating (a crossover opens one session per call)
     double *spare_binv = nullptr;
@@ -92,6 +94,34 @@ struct sx_ctx {
 
 int sx_reserve(sx_ctx *ctx, size_t bytes);  // ensure ctx->ws holds >= bytes
 int sx_reserve2(sx_ctx *ctx, size_t bytes); // ensure ctx->ws2 holds >= bytes
+int sx_reserve3(sx_ctx *ctx, size_t bytes); // ensure ctx->ws3 holds >= bytes
+
+// Device temporaries of one call carved out of ctx->ws3 (reserved once for the call's upper bound): a network solve
+// needs 25-45 arrays, and hipMalloc / hipFree cost 50-100 us apiece -- more than a small solve itself.  What does
+// not fit falls back on hipMalloc and is freed with the arena.
+struct sx_arena {
+    sx_ctx *ctx;
+    size_t off = 0;
+    std::vector<void *> extra;
+    explicit sx_arena(sx_ctx *c) : ctx(c) {}
+    ~sx_arena() {
+        for (void *q : extra) (void)hipFree(q);
+    }
+    template <class T>
+    int get(size_t count, T **out) {
+        const size_t need = (sizeof(T) * (count ? count : 1) + 255) & ~static_cast<size_t>(255);
+        if (ctx->ws3 && off + need <= ctx->ws3_bytes) {
+            *out = reinterpret_cast<T *>(static_cast<char *>(ctx->ws3) + off);
+            off += need;
+            return SX_OK;
+        }
+        void *d = nullptr;
+        SX_HIP(hipMalloc(&d, need));
+        extra.push_back(d);
+        *out = static_cast<T *>(d);
+        return SX_OK;
+    }
+};
 
 struct sx_matrix {
     sx_ctx *ctx = nullptr;

@@ -1284,21 +1284,6 @@ __global__ __launch_bounds__(256) void k_nd_outputs(int64_t V, int64_t E, const 
     if (cbasis && i < V) cbasis[i] = static_cast<int8_t>(i == root ? 0 : -1);
 }
 
-struct Pool { // device temporaries of one call
-    std::vector<void *> p;
-    ~Pool() {
-        for (void *q : p) (void)hipFree(q);
-    }
-    template <class T>
-    int get(size_t count, T **out) {
-        void *d = nullptr;
-        SX_HIP(hipMalloc(&d, sizeof(T) * (count ? count : 1)));
-        p.push_back(d);
-        *out = static_cast<T *>(d);
-        return SX_OK;
-    }
-};
-
 } // namespace
 
 SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
@@ -1316,7 +1301,9 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
         return SX_OK; // not a network: the caller takes another method
     if (ctx->opt_netdual == 0) return SX_OK;
     hipStream_t s = ctx->stream;
-    Pool pool;
+    // every temporary of the call in one block of the context (about 80 B per arc and 300 B per node)
+    SX_TRY(sx_reserve3(ctx, static_cast<size_t>(96) * static_cast<size_t>(E) + static_cast<size_t>(384) * static_cast<size_t>(V) + (1u << 20)));
+    sx_arena pool(ctx);
     NdProblem P;
     memset(&P, 0, sizeof(P));
     P.V = static_cast<int>(V);

@@ -760,21 +760,6 @@ __global__ __launch_bounds__(256) void k_ns_outputs(int64_t V, int64_t E, const 
     if (cbasis && i < V) cbasis[i] = static_cast<int8_t>(i == root ? 0 : -1);
 }
 
-struct Pool { // device temporaries of one call
-    std::vector<void *> p;
-    ~Pool() {
-        for (void *q : p) (void)hipFree(q);
-    }
-    template <class T>
-    int get(size_t count, T **out) {
-        void *d = nullptr;
-        SX_HIP(hipMalloc(&d, sizeof(T) * (count ? count : 1)));
-        p.push_back(d);
-        *out = static_cast<T *>(d);
-        return SX_OK;
-    }
-};
-
 } // namespace
 
 SX_API int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
@@ -792,7 +777,9 @@ SX_API int sx_netsimplex_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
         return SX_OK; // not a network: the caller takes the general simplex
     if (ctx->opt_netsimplex == 0) return SX_OK;
     hipStream_t s = ctx->stream;
-    Pool pool;
+    // every temporary of the call in one block of the context (about 30 B per arc and 130 B per node)
+    SX_TRY(sx_reserve3(ctx, static_cast<size_t>(40) * static_cast<size_t>(E) + static_cast<size_t>(192) * static_cast<size_t>(V) + (1u << 20)));
+    sx_arena pool(ctx);
     NsProblem P;
     memset(&P, 0, sizeof(P));
     P.V = static_cast<int>(V);
