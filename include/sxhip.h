@@ -68,7 +68,8 @@ int sx_ctx_sync(sx_ctx *ctx);
  * column walk in K1/K10: -1 auto [default: decided per matrix from its index clustering on first use],
  * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch),
  * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
- * of a batch of 32 pivots are kept in product form and folded in as one rank-32 update, -1 auto [default]),
+ * of a batch of 64 pivots are kept in product form and folded in as one rank-64 update -- by rocblas_dgemm on the
+ * fp64 matrix cores from 8192 rows on --, -1 auto [default]),
  * "spx_pricing" (entering variable of sx_simplex_solve*: 0 = Dantzig, largest reduced cost; 1 = Devex
  * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices),
  * "spx_check" (pivots between two checks of A x + s = b against the explicit inverse's drift, a multiple of 64,
@@ -364,7 +365,7 @@ int sx_mcf_arc_indicator_dev(sx_ctx *ctx, const sx_matrix *A_cols, const double 
  * network_methods/net_manager.py:222,468):
  *     min c^T x   s.t.  (A x)_i = b_i  (row_is_lt[i] == 0)  or  <= b_i  (== 1),   l <= x <= u
  * Bounded revised primal simplex, two phases, explicit dense basis inverse in HBM (8 m^2 bytes must fit the
- * free HBM, else SX_ERR_UNSUPPORTED) updated once per batch of 32 pivots and rebuilt from the basis columns
+ * free HBM, else SX_ERR_UNSUPPORTED) updated once per batch of 64 pivots and rebuilt from the basis columns
  * whenever A x + s = b fails its periodic check, Devex pricing with Bland fallback (options "spx_defer",
  * "spx_pricing", "spx_check" above).  vbasis_in[n] / cbasis_in[m] (both or neither; Gurobi codes 0 basic,
  * -1 lower, -2 upper, -3 free or superbasic / 0 basic, -1 non-basic) give a warm start: its columns are

@@ -25,7 +25,7 @@
 //                x_B -= t*dir*d;  y += (rc_q/d_r) * rho; the last workgroup to arrive (ticket, no fences)
 //                does the basis bookkeeping from values it loaded beforehand
 //   inverse      Binv -= dhat rho^T is the only O(m^2) step (16 m^2 bytes of HBM traffic).  By default it
-//                is not done per pivot: the pairs (dhat_s, rho_s) of a batch of 32 pivots are kept
+//                is not done per pivot: the pairs (dhat_s, rho_s) of a batch of 64 pivots are kept
 //                (product form: Binv_now = Binv - sum_s dhat_s rho_s^T, so FTRAN and the pivot row need
 //                one extra pass over the pending columns, without any recurrence) and k_spx_fold applies
 //                them in one pass, in pivot order -- the same fma sequence per entry as 32 rank-one
@@ -47,6 +47,8 @@
 // all-gather + lexicographic min of smart_crossover/distributed.py (one small exchange per pivot);
 // this file implements the single-device solver.
 #include "sx_internal.h"
+
+#include <rocblas/rocblas.h>
 #include "sx_segwalk.h"
 
 #include <chrono>
@@ -62,7 +64,10 @@ constexpr int SPX_CHUNK = 4096;
 constexpr int SPX_GRID = 1024;   // price workgroups (= partials) at most
 constexpr double PIV_TOL = 1e-9; // smallest |pivot| accepted
 constexpr int BLAND_AFTER = 100;
-constexpr int SPX_DEFER = 32;    // pivots whose inverse updates are held back and folded in together
+constexpr int SPX_DEFER = 64;    // pivots whose inverse updates are held back and folded in together: the fold moves
+                                 // 16 m^2 bytes, 46 % of a pivot at m = 2e4 with a batch of 32
+constexpr int SPX_BLAS_MIN_M = 8192; // from this many rows on a batch is folded in by the library DGEMM (fp64 MFMA)
+constexpr int SPX_REG = 32;      // of the pending columns, those a lane requests before the entering column is known
 
 // ST_FREE: non-basic and not at a bound -- a free variable at 0, or a *superbasic* one at the interior value
 // x[k] a starting point gave it (the reference's basis code -3).  Pricing lets it move either way; entering, it
@@ -369,9 +374,9 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
     const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x; // one row per lane (host: grid = m / SX_WG)
     const bool have = i < m;
     const int hk = have ? P.head[i] : 0;
-    double ev[SPX_DEFER];
+    double ev[SPX_REG];
 #pragma unroll
-    for (int s = 0; s < SPX_DEFER; ++s) ev[s] = (s < pending && have) ? P.E[i + s * m] : 0.0;
+    for (int s = 0; s < SPX_REG; ++s) ev[s] = (s < pending && have) ? P.E[i + s * m] : 0.0;
     const bool live = threadIdx.x < pending && P.er[threadIdx.x] >= 0;
     if (threadIdx.x < SPX_DEFER) coef[threadIdx.x] = 0.0;
     double xi = 0.0, lok = 0.0, upk = 0.0, range = INFINITY;
@@ -448,7 +453,10 @@ __global__ __launch_bounds__(SX_WG) void k_spx_ftran(Spx P, const int64_t *__res
         if (live) coef[threadIdx.x] = cs;
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < SPX_DEFER; ++s) acc = fma(-coef[s], ev[s], acc); // slots >= pending: 0 * 0
+        for (int s = 0; s < SPX_REG; ++s) acc = fma(-coef[s], ev[s], acc); // slots >= pending: 0 * 0
+        if (have)
+#pragma unroll 8
+            for (int s = SPX_REG; s < pending; ++s) acc = fma(-coef[s], P.E[i + s * m], acc); // same order as above
     }
     if (have) {
         P.d[i] = acc;
@@ -650,9 +658,9 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, in
     // independent of the pivot row
     const int hk = have ? P.head[i] : 0;
     const double di = have ? P.d[i] : 0.0, yi = have ? P.y[i] : 0.0;
-    double rv[SPX_DEFER];
+    double rv[SPX_REG];
 #pragma unroll
-    for (int s = 0; s < SPX_DEFER; ++s) rv[s] = (s < pending && have) ? P.R[i + s * m] : 0.0;
+    for (int s = 0; s < SPX_REG; ++s) rv[s] = (s < pending && have) ? P.R[i + s * m] : 0.0;
     const bool live = threadIdx.x < pending && P.er[threadIdx.x] >= 0;
     if (threadIdx.x < SPX_DEFER) w[threadIdx.x] = 0.0;
     if (st->done) {
@@ -686,7 +694,10 @@ __global__ __launch_bounds__(SX_WG) void k_spx_rho_update(Spx P, int pending, in
         if (live) w[threadIdx.x] = P.E[r + threadIdx.x * m];
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < SPX_DEFER; ++s) rho_i = fma(-w[s], rv[s], rho_i); // slots >= pending: 0 * 0
+        for (int s = 0; s < SPX_REG; ++s) rho_i = fma(-w[s], rv[s], rho_i); // slots >= pending: 0 * 0
+        if (have)
+#pragma unroll 8
+            for (int s = SPX_REG; s < pending; ++s) rho_i = fma(-w[s], P.R[i + s * m], rho_i);
     }
     if (have) {
         // the leaving variable is set to its bound by the bookkeeping, which may run in another workgroup:
@@ -731,27 +742,61 @@ __global__ __launch_bounds__(SX_WG) void k_spx_fold(Spx P, int cnt, int col_tile
     for (int s = 0; s < SPX_DEFER; ++s) ev[s] = (s < cnt && i < m) ? P.E[i + s * m] : 0.0;
     __syncthreads();
     if (i >= m) return;
-    // two columns at a time: two loads in flight and two independent fma chains per lane (no further
-    // unrolling: it would take the registers that keep several waves per SIMD resident)
+    // four columns at a time: four loads in flight and four independent fma chains per lane (the lane's row of E
+    // takes 2 * SPX_DEFER registers, so few waves share a SIMD and each has to keep more bytes in flight)
     double *col = P.Binv + i + k0 * m;
     int kk = 0;
 #pragma unroll 1
-    for (; kk + 2 <= ncol; kk += 2, col += 2 * m) {
-        double v0 = col[0], v1 = col[m];
+    for (; kk + 4 <= ncol; kk += 4, col += 4 * m) {
+        double v0 = col[0], v1 = col[m], v2 = col[2 * m], v3 = col[3 * m];
 #pragma unroll
         for (int s = 0; s < SPX_DEFER; ++s) {
             v0 = fma(-ev[s], rt[s][kk], v0);
             v1 = fma(-ev[s], rt[s][kk + 1], v1);
+            v2 = fma(-ev[s], rt[s][kk + 2], v2);
+            v3 = fma(-ev[s], rt[s][kk + 3], v3);
         }
         col[0] = v0;
         col[m] = v1;
+        col[2 * m] = v2;
+        col[3 * m] = v3;
     }
-    if (kk < ncol) {
+#pragma unroll 1
+    for (; kk < ncol; ++kk, col += m) {
         double v0 = col[0];
 #pragma unroll
         for (int s = 0; s < SPX_DEFER; ++s) v0 = fma(-ev[s], rt[s][kk], v0);
         col[0] = v0;
     }
+}
+
+// A batch's fold as ONE library DGEMM, Binv -= E R^T (m x m, K = SPX_DEFER), on the fp64 matrix cores: the kernel
+// above reads an LDS operand per fma and is issue-bound beyond 32 pending updates (2.2 ms for 64 at m = 2e4, the
+// traffic alone would be 1.3 ms); rocBLAS does the rank-64 update in 1.46 ms (profiles/r02/spx_fold.md).  Slots in
+// which no pivot was recorded (bound flips, the tail of a finished batch) still hold an older batch's columns:
+// they are zeroed first.
+__global__ __launch_bounds__(SX_WG) void k_spx_fold_mask(Spx P, int cnt) {
+    const int sl = blockIdx.y;
+    if (sl < cnt && P.er[sl] >= 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    if (i < P.m) {
+        P.E[i + sl * P.m] = 0.0;
+        P.R[i + sl * P.m] = 0.0;
+    }
+}
+
+rocblas_handle spx_blas(int device, hipStream_t s) { // one handle per device, made on first use
+    static rocblas_handle handles[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    if (!handles[device]) {
+        if (rocblas_create_handle(&handles[device]) != rocblas_status_success) {
+            handles[device] = nullptr;
+            return nullptr;
+        }
+        (void)rocblas_set_pointer_mode(handles[device], rocblas_pointer_mode_host);
+    }
+    if (rocblas_set_stream(handles[device], s) != rocblas_status_success) return nullptr;
+    return handles[device];
 }
 
 // Binv -= dhat * rho^T with dhat_i = d_i/alpha (i != r), dhat_r = (alpha - 1)/alpha
@@ -1356,7 +1401,19 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
     };
     const int fold_col_tiles = static_cast<int>((m + FOLD_COLS - 1) / FOLD_COLS);
     const unsigned fold_grid = static_cast<unsigned>(((m + SX_WG - 1) / SX_WG) * fold_col_tiles);
+    // large inverses fold through the library DGEMM (never inside a stream capture: see enqueue_batch)
+    static const char *blas_env = getenv("SX_SPX_BLAS"); // "0": the library's own fold kernel at every size (A/B runs)
+    rocblas_handle blas = (defer && m >= SPX_BLAS_MIN_M && !(blas_env && blas_env[0] == '0')) ? spx_blas(ctx->device, s) : nullptr;
     auto fold = [&](int cnt) {
+        if (blas) {
+            hipLaunchKernelGGL(k_spx_fold_mask, dim3(gM, SPX_DEFER), dim3(SX_WG), 0, s, P, cnt);
+            const double alpha = -1.0, beta = 1.0;
+            if (rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, static_cast<rocblas_int>(m),
+                              static_cast<rocblas_int>(m), SPX_DEFER, &alpha, P.E, static_cast<rocblas_int>(m), P.R,
+                              static_cast<rocblas_int>(m), &beta, P.Binv, static_cast<rocblas_int>(m)) == rocblas_status_success)
+                return;
+            blas = nullptr; // (the columns are masked: the kernel below does the same update)
+        }
         hipLaunchKernelGGL(k_spx_fold, dim3(fold_grid), dim3(SX_WG), 0, s, P, cnt, fold_col_tiles);
     };
     double host_meas[3] = {0, 0, 0};
@@ -1540,18 +1597,18 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
         hipLaunchKernelGGL(k_spx_rho_update, dim3(gM), dim3(SX_WG), 0, s, P, defer ? k : 0, defer ? k : -1);
         if (!defer) hipLaunchKernelGGL(k_spx_update_binv, dim3(gMM), dim3(SX_WG), 0, s, P);
     };
-    auto enqueue_batch = [&]() {
+    auto enqueue_batch = [&](bool with_fold = true) {
         for (int k = 0; k < batch; ++k) enqueue_pivot(k);
-        if (defer) fold(batch);
+        if (defer && with_fold) fold(batch);
     };
-    // a batch of 32 pivots = 96 small launches (+ the fold) with fixed arguments: captured into a hipGraph and
+    // a batch of 64 pivots = 192 small launches (+ the fold) with fixed arguments: captured into a hipGraph and
     // replayed (pivots are launch-bound for small m); direct launches are the fallback.  Capturing and
     // instantiating costs milliseconds, more than a short warm-started re-solve takes altogether, so the
     // graph is only built once a solve has gone through GRAPH_AFTER pivots by direct launches.
     const int64_t GRAPH_AFTER = 4096; // with 3 launches per pivot replay only insures against a slow host
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    bool graph_tried = false;
+    bool graph_tried = false, graph_has_fold = true;
     auto build_graph = [&]() {
         graph_tried = true;
         if (!ctx->opt_graph) return;
@@ -1560,7 +1617,8 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
         // (profiles/r01/spx_bench.txt), so a profiled run simply does not replay
         if (getenv("ROCP_TOOL_LIBRARIES") != nullptr) return;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            enqueue_batch();
+            graph_has_fold = blas == nullptr;
+            enqueue_batch(graph_has_fold); // a library call stays out of the capture: it follows the replay
             if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
                 hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 exec = nullptr;
@@ -1594,6 +1652,7 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
             if (!exec) direct_pivots += batch;
             if (exec) {
                 SX_HIP(hipGraphLaunch(exec, s));
+                if (defer && !graph_has_fold) fold(batch);
             } else {
                 enqueue_batch();
             }
