@@ -670,6 +670,15 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
         delete h;
         return rc;
     }
+    struct Guard { // a failed launch below must not leak the handle and its block
+        sx_cg_shard *h;
+        ~Guard() {
+            if (h) {
+                (void)hipFree(h->block);
+                delete h;
+            }
+        }
+    } guard{h};
     h->st = reinterpret_cast<CgState *>(h->block);
     h->ppq = reinterpret_cast<double *>(h->block + off_ppq);
     h->prr = reinterpret_cast<double *>(h->block + off_prr);
@@ -689,6 +698,7 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
         SX_HIP(hipMemsetAsync(h->q, 0, sizeof(double) * static_cast<size_t>(m), s));
     }
     SX_HIP(hipGetLastError());
+    guard.h = nullptr;
     *out = h;
     *reduce_vec = h->q;
     return SX_OK;

@@ -297,7 +297,10 @@ __global__ __launch_bounds__(256) void k_nd_ordrec(NdProblem P) {
 
 // the tree arrays kept from the previous solve describe THIS basis iff every node's arc is coded basic and joins it to
 // its parent (V - 1 distinct tree arcs out of the V - 1 the basis has)
-__global__ __launch_bounds__(256) void k_nd_check_kept(NdProblem P, int *__restrict__ differs) {
+// The kept potentials belong to the costs of the solve that left them: a tree arc whose reduced cost under
+// THIS call's costs is not zero (to rounding: the potentials were shifted subtree by subtree) means the costs
+// changed -- re-scaled, perturbed, another instance on the same graph -- and the tree set-up has to run again.
+__global__ __launch_bounds__(256) void k_nd_check_kept(NdProblem P, const double *__restrict__ y_kept, int *__restrict__ differs) {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= P.V) return;
     const int4 r = P.nd[w];
@@ -309,6 +312,11 @@ __global__ __launch_bounds__(256) void k_nd_check_kept(NdProblem P, int *__restr
         if (ok) {
             const int t = P.tail[r.y], h = P.head[r.y];
             ok = (t == w && h == r.x) || (h == w && t == r.x);
+            if (ok) {
+                const double c = P.cost[r.y], yt = y_kept[t], yh = y_kept[h];
+                const double rc = (c - yt) + yh;
+                ok = fabs(rc) <= 1e-10 * (1.0 + fabs(c) + fabs(yt) + fabs(yh)); // (NaN fails the test)
+            }
         }
     }
     if (!ok) *differs = 1;
@@ -1381,7 +1389,14 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
         SX_TRY(pool.get(V > ND_GMAX ? V : ND_GMAX, &P.acc[k]));
         SX_TRY(pool.get(V, &P.anc[k]));
     }
-    hipEvent_t ev[3];
+    struct Events { // destroyed on every return path
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() {
+            for (hipEvent_t x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+        hipEvent_t &operator[](int k) { return e[k]; }
+    } ev;
     for (int k = 0; k < 3; ++k) SX_HIP(hipEventCreate(&ev[k]));
     SX_HIP(hipEventRecord(ev[0], s));
     // ---- set-up: tree, potentials, dual feasibility by flips, tree flows
@@ -1389,7 +1404,7 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
         int *d_differs;
         SX_TRY(pool.get(1, &d_differs));
         SX_HIP(hipMemsetAsync(d_differs, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_nd_check_kept, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, d_differs);
+        hipLaunchKernelGGL(k_nd_check_kept, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, ctx->nd_y, d_differs);
         int differs = 0;
         SX_HIP(hipMemcpyAsync(&differs, d_differs, sizeof(int), hipMemcpyDeviceToHost, s));
         SX_HIP(hipStreamSynchronize(s));
@@ -1403,10 +1418,7 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     SX_HIP(hipGetLastError());
     SX_HIP(hipMemcpyAsync(&sh, P.sh, sizeof(sh), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
-    if (sh.status == 5 || sh.not_network) { // not a tree / an uncapacitated arc would have to flip
-        for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
-        return SX_OK;
-    }
+    if (sh.status == 5 || sh.not_network) return SX_OK; // not a tree / an uncapacitated arc would have to flip
     hipLaunchKernelGGL(k_nd_ordrec, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P); // (order[] is valid now)
     SX_TRY(sx_score_rows_dev(ctx, A, xn, b, nullptr, 0.0, beff, nullptr)); // b - A x_N, sums in stored order
     hipLaunchKernelGGL(k_nd_excess, dim3(static_cast<unsigned>((V + 255) / 256)), dim3(256), 0, s, P, beff);
@@ -1453,7 +1465,6 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     float ms_setup = 0.f, ms_solve = 0.f;
     (void)hipEventElapsedTime(&ms_setup, ev[0], ev[1]);
     (void)hipEventElapsedTime(&ms_solve, ev[1], ev[2]);
-    for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
     if (getenv("SX_NS_PROFILE"))
         fprintf(stderr, "[sx_netdual] V=%lld E=%lld grid=%d iterations=%lld flips=%lld status=%lld | set-up %.1f ms, solve %.1f ms | "
                         "us per iteration: pass %.2f wide cut %.2f cut %.2f ratio %.2f publish %.2f (pass compute %.2f) barriers %.2f (pass loads %.2f) | per iteration: "

@@ -238,8 +238,13 @@ class HipOps:
         from smart_crossover.hip import lib as _l
         cols, rows, res = C.c_double(0), C.c_double(0), _l.CgResult()
         _l.check(self.ctx._lib.sx_cg_shard_finish(s["h"], None, None, C.byref(cols), C.byref(rows), C.byref(res)))
-        _l.check(self.ctx._lib.sx_cg_shard_close(s["h"]))
         return float(cols.value), float(rows.value), int(res.iters), bool(res.converged)
+
+    def cg_close(self, s) -> None:
+        """Releases the handle and its device block (idempotent; the caller's ``finally``)."""
+        h = s.pop("h", None)
+        if h is not None:
+            self.ctx._lib.sx_cg_shard_close(h)
 
     # ---- MCF kernels
     def mcf_xhat(self, x, u, xhat, mask):
@@ -343,21 +348,28 @@ class ShardedLP:
         per CG iteration.  ``xa`` (n) and ``xs`` (m) are replicated host vectors."""
         o = self.ops
         cs, ce = self.cols.start, self.cols.stop
-        s = o.cg_open(self.A_cols, o.vec(xa[cs:ce]), o.vec(xs), self.c_loc, tol)
-        self._allreduce(s["q"])
-        bnorm, trivial = o.cg_start(s)
-        it = 0
-        done = trivial
-        while not done and it < maxiter:
-            upto = min(it + poll, maxiter)
-            for k in range(it, upto):
-                o.cg_local(s)
-                self._allreduce(s["q"])
-                o.cg_update(s, k)
-            it = upto
-            done, _ = o.cg_poll(s)
-        cols, rows, iters, converged = o.cg_finish(s)
         import torch
+        s = o.cg_open(self.A_cols, o.vec(xa[cs:ce]), o.vec(xs), self.c_loc, tol)
+        try:
+            self._allreduce(s["q"])
+            bnorm, trivial = o.cg_start(s)
+            it = 0
+            done = self._agreed(trivial)
+            while not done and it < maxiter:
+                upto = min(it + poll, maxiter)
+                for k in range(it, upto):
+                    o.cg_local(s)
+                    self._allreduce(s["q"])
+                    o.cg_update(s, k)
+                it = upto
+                # every all_reduce above is a collective: the ranks must leave the loop together, so the flag
+                # each rank reads from its own device is itself reduced (MAX: stop as soon as any rank stops)
+                done = self._agreed(o.cg_poll(s)[0])
+            cols, rows, iters, converged = o.cg_finish(s)
+        finally:
+            close = getattr(o, "cg_close", None)
+            if close is not None:
+                close(s)
         t = torch.tensor([cols], dtype=torch.float64, device=getattr(o, "device", "cpu"))
         self._allreduce(t)
         return float(np.sqrt(float(t.item()) + rows)), iters, converged
@@ -365,6 +377,15 @@ class ShardedLP:
     def _allreduce(self, t):
         if self.dist is not None:
             self.dist.all_reduce(t)
+
+    def _agreed(self, flag) -> bool:
+        """The same yes/no on every rank: MAX over the ranks of a one-element int tensor."""
+        if self.dist is None:
+            return bool(flag)
+        import torch
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=getattr(self.ops, "device", "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
 
     def _allgather(self, t, sizes: Sequence[int]):
         """Concatenation of every rank's 1-D tensor (blocks may differ in length)."""

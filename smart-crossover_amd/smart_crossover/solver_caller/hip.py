@@ -192,7 +192,7 @@ class HipCaller(SolverCaller):
             else:
                 res = ctx.net_simplex(dA, d_b, d_c, d_l, d_u, vb_in, cb_in, 0, 1e-7, float(self.settings.optimalityTol),
                                       d_x, d_y, d_vb, d_cb)
-                if int(res.status) != 5:
+                if int(res.status) in (0, 1, 2):     # (3, 4, 5: the general simplex below takes over from vb_in / cb_in)
                     self._res, self.solved_by = res, "netsimplex"
         if self._res is None:
             self._res = ctx.simplex(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt),
@@ -282,6 +282,15 @@ class SplitCaller(SolverCaller):
     def read_stdlp(self, stdlp):
         self._bar.read_stdlp(stdlp)
         self._spx.read_stdlp(stdlp)
+
+    def read_mcf(self, mcf):
+        # both backends get to see that the problem is a network (HipCaller.read_mcf selects K16d / K16n)
+        self._bar.read_mcf(mcf)
+        self._spx.read_mcf(mcf)
+
+    def read_ot(self, ot):
+        self._bar.read_ot(ot)
+        self._spx.read_ot(ot)
 
     def add_warm_start_basis(self, basis):
         self._spx.add_warm_start_basis(basis)

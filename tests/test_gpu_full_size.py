@@ -228,4 +228,47 @@ def test_config2_perturbation_crossover_end_to_end_on_the_device():
     x_full = mgr.get_orix(x)
     obj_interior = float(lp.c @ inst.x)
     gap = abs(float(lp.c @ x_full) - obj_interior) / (abs(float(lp.c @ x_full)) + abs(obj_interior) + 1)
-    assert gap < 1e-5
+    assert gap < 1e-8                                                # PRIMAL_DUAL_GAP_THRESHOLD (parameters.py:26)
+
+
+def test_config5_projector_cg_history_against_the_oracle(ctx):
+    """K4 at full config-5 size (1e6 x 1e7, 8e7 entries): the first 20 CG iterations of the projector against the
+    CPU statement of the same algorithm (oracle.lp_path.cg_legacy on the matrix-free operator) -- ||proj|| and the
+    relative residual after 5, 10 and 20 iterations, 1e-9 relative (the two sides sum in different orders)."""
+    sh = workloads.lp_shard(0, 1)
+    m, n = sh.m, sh.n_block
+    rng = np.random.default_rng(11)
+    sense = np.where(rng.random(m) < 0.5, "<", "=")
+    A = sh.row_block
+    xr = L.x_perturb_val(sh.x, sh.l, sh.u)
+    xx = L.standard_x(A, sh.b, sense, xr)
+    rows = L.slack_rows(sense)
+    xa, xs_c = xx[:n], xx[n:]
+    xs = np.zeros(m)
+    xs[rows] = xs_c
+    C = sh.col_block                                   # CSC of A = CSR of A^T, same arrays
+    AT = sp.csr_matrix((C.data, C.indices, C.indptr), shape=(n, m))
+    c_std = L.standard_c(sh.c, sense)
+    v = xx * c_std
+
+    def Yt(p):
+        return np.concatenate([xa * (AT @ p), xs_c * p[rows]])
+
+    def Ymul(w):
+        out = A @ (xa * w[:n])
+        out[rows] += xs_c * w[n:]
+        return out
+
+    Yv = Ymul(v)
+    bn = float(np.linalg.norm(Yv))
+    dA = ctx.matrix(A)
+    d_xa, d_xs, d_c = ctx.to_device(xa), ctx.to_device(xs), ctx.to_device(sh.c)
+    for iters in (5, 10, 20):
+        res = ctx.projector_norm(dA, d_xa, d_xs, d_c, 1e-8, iters)
+        z, it, conv = L.cg_legacy(lambda p: Ymul(Yt(p)), Yv, 1e-8, iters)
+        assert it == iters == int(res.iters) and not conv and int(res.converged) == 0
+        proj = v - Yt(z)
+        rel = float(np.linalg.norm(Yv - Ymul(Yt(z)))) / bn
+        assert res.proj_norm == pytest.approx(float(np.linalg.norm(proj)), rel=1e-9)
+        assert res.rel_residual == pytest.approx(rel, rel=1e-6)      # (a difference of nearly equal vectors)
+    dA.free()

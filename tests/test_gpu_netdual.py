@@ -216,3 +216,27 @@ def test_uncapacitated_networks_go_to_the_primal_method_at_once(ctx):
         assert int(run(ctx, A, b, c, u, vb, cb)[0].status) == 5       # wrong-signed uncapacitated arcs
     finally:
         ctx.set_option("netdual", -1)
+
+
+def test_kept_tree_with_changed_costs_recomputes_the_potentials(ctx):
+    """Solve, change the costs, solve again from the basis handed back: the tree arrays kept in the context are the
+    same tree, but the kept potentials belong to the OLD costs -- the set-up has to run again (the kept path is
+    taken only when every tree arc has reduced cost zero under the costs of this call)."""
+    V, E = 300, 3000
+    A, b, c, u, tail, head, vb, cb = big_m_network(V, E, 2, inf_frac=0.0)
+    res, x, y, vbo, cbo = run(ctx, A, b, c, u, vb, cb)
+    assert int(res.status) == 0
+    rng = np.random.default_rng(9)
+    c2 = c.copy()
+    c2[:E] = rng.integers(1, 50, size=E).astype(np.float64)        # new arc costs, same graph, same big-M arcs
+    res2, x2, y2, vb2, cb2 = run(ctx, A, b, c2, u, vbo.astype(np.int8), cbo.astype(np.int8))
+    assert int(res2.status) == 0
+    assert int(res2.warm_start_used) == 1                           # kept potentials rejected, tree set up again
+    want = dual_network_simplex(tail, head, c2, u, b, vbo, root=V)
+    same_pivots(res2, x2, vb2, want)
+    certificates(A, b, c2, u, tail, head, x2, y2, vb2, cb2)
+    assert float(res2.obj) == pytest.approx(highs(A, b, c2, u), rel=1e-9, abs=1e-9)
+    # unchanged costs afterwards: the kept path is taken again
+    res3, x3, _, vb3, _ = run(ctx, A, b, c2, u, vb2.astype(np.int8), cb2.astype(np.int8))
+    assert int(res3.status) == 0 and int(res3.iters) == 0 and int(res3.warm_start_used) == 2
+    assert np.array_equal(x3, x2)

@@ -187,3 +187,28 @@ def test_cnet_mcf_runs_on_the_network_simplex_and_agrees_with_highs(ctx, V, E, n
     capsys.readouterr()
     assert used and all(how == ("netsimplex" if netdual == 0 else "netdual") for how in used)
     assert costs["HIP"] == pytest.approx(costs["HGS"], rel=1e-9)
+
+
+def test_composite_backend_keeps_the_network_route(ctx, capsys):
+    """'HGS+HIP': ``SplitCaller`` forwards ``read_mcf`` to both backends, so the device still sees a network and the
+    re-solves of CNET_MCF go to K16d / K16n -- not to the general simplex with its dense inverse."""
+    from smart_crossover.formats import MinCostFlow
+    from smart_crossover.network_methods.algorithms import network_crossover
+    from smart_crossover.solver_caller import hip as hipmod
+    used = []
+    orig = hipmod.HipCaller._solve
+
+    def spy(self):
+        orig(self)
+        used.append(self.solved_by)
+
+    hipmod.HipCaller._solve = spy
+    try:
+        inst = workloads.mcf(512, 4096, 3)
+        mcf = MinCostFlow(A=inst.A.copy(), b=inst.b.copy(), c=inst.c.copy(), u=inst.u.copy())
+        out = network_crossover(inst.x.copy(), mcf=mcf, method="cnet_mcf", solver="HGS+HIP")
+    finally:
+        hipmod.HipCaller._solve = orig
+    capsys.readouterr()
+    assert out.status == "OPTIMAL"
+    assert used and all(how in ("netdual", "netsimplex") for how in used)

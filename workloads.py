@@ -413,3 +413,66 @@ def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_00
     b = row_block @ x + slack[r0:r0 + m_loc]
     return LPShard(rank=rank, world=world, m=m, n_block=n_block, col_block=col_block, row_block=row_block, y=y, x=x,
                    c=c, l=l, u=u, b=b)
+
+
+# --------------------------------------------------------------------------
+# N1: the configuration BASELINE.json's metric is quoted on ("1e6-variable netlib-style LP")
+# --------------------------------------------------------------------------
+def netlib_lp(m: int = 100_000, n: int = 1_000_000, seed: int = 6, window: int = 512,
+              frac_lt: float = 0.5, frac_upper: float = 0.25, name: Optional[str] = None) -> LPInstance:
+    """A *consistent* netlib-style (staircase + linking rows) LP with a synthetic late-barrier iterate.
+
+    Structure as in ``_staircase_blocks`` (8 entries per column: six in a window of ``window`` stage rows
+    at the column's home position, one in the following window, one in a linking row; 1 % of the rows are
+    linking rows; home positions grow with the column index), vectors as in ``sparse_lp`` -- so, unlike
+    ``lp_shard`` (a kernel workload whose senses are drawn independently of its slacks), (x, y) here IS a
+    strictly complementary primal-dual pair of the LP to 1e-9: b = A x + slack with slack > 0 only on '<'
+    rows whose dual is ~0, c = A^T y + s_d with s_d ~ 1e-10 on the ~m "basic" columns.  The basic columns
+    are one of every n/m consecutive columns (random offset), so every stretch of stage rows keeps its
+    share of them and the restricted sub-problem the crossover builds stays feasible."""
+    rng = np.random.default_rng(seed)
+    nl = max(1, m // 100)                       # linking rows, at the head of the row range
+    ms = m - nl
+    W = max(12, min(window, ms // 4))
+    ws = W // 6
+    j = np.arange(n, dtype=np.int64)
+    home = (j * (ms - 2 * W) // n).astype(np.int64)
+    idx = np.empty((n, 8), dtype=np.int32)
+    val = rng.uniform(-1.0, 1.0, size=(n, 8))
+    val[np.abs(val) < 1e-3] = 0.5
+    idx[:, 0] = rng.integers(0, nl, size=n)
+    for t in range(6):
+        idx[:, 1 + t] = nl + home + t * ws + rng.integers(0, ws, size=n)
+    idx[:, 7] = nl + home + W + rng.integers(0, W, size=n)
+    colptr = np.arange(n + 1, dtype=np.int64) * 8
+    A = sp.csc_matrix((val.ravel(), idx.ravel(), colptr), shape=(m, n)).tocsr()
+    A.sort_indices()
+
+    y = rng.standard_normal(m)
+    sense = np.where(rng.random(m) < frac_lt, "<", "=")
+    lt = sense == "<"
+    y[lt] = np.where(rng.random(int(lt.sum())) < 0.5, -np.abs(y[lt]), 1e-11 * np.abs(y[lt]))
+    l = np.zeros(n)
+    u = np.full(n, np.inf)
+    has_up = rng.random(n) < frac_upper
+    u[has_up] = rng.uniform(1.0, 10.0, int(has_up.sum()))
+    group = max(1, n // m)
+    basic = np.zeros(n, dtype=bool)
+    starts = np.arange(0, n - group + 1, group, dtype=np.int64)
+    basic[starts + rng.integers(0, group, size=starts.size)] = True
+    x = np.full(n, 1e-9)
+    x[basic] = rng.uniform(0.1, 1.0, int(basic.sum()))
+    at_up = (~basic) & has_up & (rng.random(n) < 0.5)
+    x[at_up] = u[at_up] - 1e-9
+    s_d = np.abs(rng.standard_normal(n))
+    s_d[basic] = 1e-10 * rng.random(int(basic.sum()))
+    s_d[at_up] = -s_d[at_up]
+    c = A.T @ y + s_d
+    slack = np.zeros(m)
+    loose = lt & (y > -1e-9)
+    slack[loose] = rng.uniform(0.1, 1.0, int(loose.sum()))
+    tight = lt & ~loose
+    slack[tight] = 1e-10 * rng.random(int(tight.sum()))
+    b = A @ x + slack
+    return LPInstance(A=A, b=b, c=c, l=l, u=u, sense=sense, x=x, y=y,
+                      name=name or f"netlib_{m}x{n}")
