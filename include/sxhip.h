@@ -401,6 +401,32 @@ int sx_simplex_crossover_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, c
                              double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
                              sx_simplex_result *result);
 
+/* First-order stage of the same re-solve (K16p, csrc/sx_pdlp.hip): what the reference's backends do with
+ * "barrier" before their crossover (lp_methods/algorithms.py:50-54 -> solver_caller/gurobi.py:111-115) -- carry
+ * the interior point of the original LP next to the optimum of the PERTURBED sub-problem, so that the crossover
+ * (sx_simplex_crossover_dev) needs few pivots.  Restarted, diagonally preconditioned primal-dual hybrid gradient
+ * (PDLP) on  min c^T x, A x (= | <=) b, l <= x <= u  from (x0, y0) (either may be NULL = 0): per iteration one walk
+ * of the column layout and one of the row layout with the proximal steps fused in; KKT errors of iterate and
+ * running average, restart decision and primal weight every 64 iterations on the device; stops when primal
+ * residual <= tol (1 + ||b||), dual residual <= tol (1 + ||c||) and gap <= tol (1 + |p| + |d|), or after max_iter
+ * iterations (<= 0: 20000; rounded up to a multiple of 64).  Outputs x[n] (inside its bounds; at a bound exactly
+ * where the projection put it) and y[m] (reduced cost = c - A^T y, y <= 0 on '<' rows).  Blocking; arrays device.
+ * Third-party counterpart absent (Gurobi's barrier): parity unpinned; oracle/pdlp.py states the iteration. */
+typedef struct sx_pdlp_result {
+    int64_t status;          /* 0 converged to tol, 3 iteration limit */
+    int64_t iters;
+    int64_t restarts;
+    double primal_residual;  /* || violation of A x (=|<=) b ||_2 */
+    double dual_residual;    /* || part of c - A^T y no bound can absorb ||_2 */
+    double gap;              /* | c^T x - (b^T y + l^T rc+ + u^T rc-) | */
+    double primal_obj, dual_obj;
+    double b_norm, c_norm;
+    double step, primal_weight;
+} sx_pdlp_result;
+int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l, const double *u,
+                const uint8_t *row_is_lt, const double *x0, const double *y0, int64_t max_iter, double tol, double *x,
+                double *y, sx_pdlp_result *result);
+
 /* Network simplex (K16n) for the re-solves of the network crossover (network_methods/net_manager.py:211-222
  * solve_subproblem -> solve_mcf / solve_ot with warm_start_basis; the reference hands these to Gurobi's /
  * CPLEX's simplex).  A must be a node-arc incidence matrix -- every column exactly one +1 (tail row) and one

@@ -263,6 +263,13 @@ class Context:
             _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
 
+    def pdlp(self, A, b, c, l, u, row_is_lt, x0=None, y0=None, max_iter=0, tol=1e-8, x=None, y=None) -> "_l.PdlpResult":
+        """K16p (blocking): first-order stage of the LP re-solve (restarted PDHG) from (x0, y0); device pointers."""
+        res = _l.PdlpResult()
+        _l.check(self._lib.sx_pdlp_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt),
+                                       _ptr(x0), _ptr(y0), int(max_iter), float(tol), _ptr(x), _ptr(y), C.byref(res)))
+        return res
+
     def net_simplex(self, A, b, c, l, u, vbasis, cbasis, max_iter=0, feas_tol=1e-7, opt_tol=1e-7, x=None, y=None,
                     vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
         """K16n (blocking): primal network simplex from a spanning-tree basis; status 5 = the problem or the

@@ -45,6 +45,12 @@ class SimplexResult(C.Structure):
                 ("warm_start_used", C.c_int64), ("obj", C.c_double), ("max_violation", C.c_double)]
 
 
+class PdlpResult(C.Structure):
+    _fields_ = [("status", C.c_int64), ("iters", C.c_int64), ("restarts", C.c_int64), ("primal_residual", C.c_double),
+                ("dual_residual", C.c_double), ("gap", C.c_double), ("primal_obj", C.c_double), ("dual_obj", C.c_double),
+                ("b_norm", C.c_double), ("c_norm", C.c_double), ("step", C.c_double), ("primal_weight", C.c_double)]
+
+
 class SinkhornResult(C.Structure):
     _fields_ = [("iters", C.c_int64), ("status", C.c_int64), ("err", C.c_double)]
 
@@ -123,6 +129,7 @@ PROTOTYPES = {
                                     C.POINTER(SimplexResult)]),
     "sx_simplex_crossover_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                         C.POINTER(SimplexResult)]),
+    "sx_pdlp_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp, C.POINTER(PdlpResult)]),
     "sx_netsimplex_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  C.POINTER(SimplexResult)]),
     "sx_netdual_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp,

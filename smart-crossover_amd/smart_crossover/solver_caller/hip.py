@@ -22,6 +22,7 @@ the free HBM, i.e. about 1.7e5 rows on an empty MI355X.
 from __future__ import annotations
 
 import datetime
+import os
 import time
 from typing import Optional, Tuple
 
@@ -35,6 +36,8 @@ from smart_crossover.solver_caller.caller import SolverCaller, SolverSettings
 _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
 
+PDLP_ITERS = 20000       # first-order stage in front of the crossover ('barrier' runs): iteration limit (0: skip it)
+PDLP_TOL = 1e-9          # ... and its relative KKT tolerance
 NETDUAL_FEAS_TOL = 1e-9  # bound violation of a tree arc the dual network simplex still calls feasible
 CRASH_MARGIN = 1e-6      # a column this far (relative) inside its bounds / a slack this large counts as basic
 
@@ -164,7 +167,22 @@ class HipCaller(SolverCaller):
         d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
         d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
         vb_in = cb_in = x_start = None
+        t0 = time.perf_counter()
+        d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
+        self.pdlp = None
         if self._warm is None and getattr(self, "_want_crash", False):
+            iters = int(os.environ.get("SX_PDLP_ITERS", PDLP_ITERS))
+            if self._warm_point is not None and iters > 0 and np.asarray(self._warm_point[0]).size == n:
+                # what the reference's backends do with 'barrier' before their crossover: carry the interior point
+                # of the original LP next to the optimum of THIS (perturbed) LP -- first-order stage K16p
+                x0 = np.clip(np.asarray(self._warm_point[0], dtype=np.float64), self._l, self._u)
+                y0 = np.asarray(self._warm_point[1], dtype=np.float64)
+                y0 = np.where(self._row_lt.astype(bool), np.minimum(y0, 0.0), y0) if y0.size == m else np.zeros(m)
+                d_px, d_py = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+                self.pdlp = ctx.pdlp(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), put(x0), put(y0), iters,
+                                     float(os.environ.get("SX_PDLP_TOL", PDLP_TOL)), d_px, d_py)
+                self._warm_point = (d_px.download(), d_py.download())
+                self.pdlp_seconds = time.perf_counter() - t0
             self._warm = self._crash_basis(ctx, dA)
             if self._warm is not None:          # crossover: start AT the interior point (superbasic columns)
                 x_start = ctx.to_device(np.ascontiguousarray(self._warm_point[0], dtype=np.float64))
@@ -177,8 +195,6 @@ class HipCaller(SolverCaller):
             if getattr(holder, "session", None) is None:
                 holder.session = ctx.simplex_session()
             session = holder.session
-        t0 = time.perf_counter()
-        d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
         self._res = None
         self.solved_by = "simplex"
         if self._network and vb_in is not None and x_start is None and not self._row_lt.any():

@@ -221,22 +221,30 @@ def test_uncapacitated_networks_go_to_the_primal_method_at_once(ctx):
 def test_kept_tree_with_changed_costs_recomputes_the_potentials(ctx):
     """Solve, change the costs, solve again from the basis handed back: the tree arrays kept in the context are the
     same tree, but the kept potentials belong to the OLD costs -- the set-up has to run again (the kept path is
-    taken only when every tree arc has reduced cost zero under the costs of this call)."""
+    taken only when every tree arc has reduced cost zero under the costs of this call).  Doubling every cost
+    (network_methods/net_manager.py:276-283 rescale_cost is such a change) keeps the optimal tree optimal: no
+    iteration, the same flows, potentials doubled; then a change of the non-tree costs that asks for pivots."""
     V, E = 300, 3000
     A, b, c, u, tail, head, vb, cb = big_m_network(V, E, 2, inf_frac=0.0)
     res, x, y, vbo, cbo = run(ctx, A, b, c, u, vb, cb)
     assert int(res.status) == 0
-    rng = np.random.default_rng(9)
-    c2 = c.copy()
-    c2[:E] = rng.integers(1, 50, size=E).astype(np.float64)        # new arc costs, same graph, same big-M arcs
-    res2, x2, y2, vb2, cb2 = run(ctx, A, b, c2, u, vbo.astype(np.int8), cbo.astype(np.int8))
-    assert int(res2.status) == 0
+    res2, x2, y2, vb2, cb2 = run(ctx, A, b, 2.0 * c, u, vbo.astype(np.int8), cbo.astype(np.int8))
+    assert int(res2.status) == 0 and int(res2.iters) == 0
     assert int(res2.warm_start_used) == 1                           # kept potentials rejected, tree set up again
-    want = dual_network_simplex(tail, head, c2, u, b, vbo, root=V)
-    same_pivots(res2, x2, vb2, want)
-    certificates(A, b, c2, u, tail, head, x2, y2, vb2, cb2)
-    assert float(res2.obj) == pytest.approx(highs(A, b, c2, u), rel=1e-9, abs=1e-9)
+    assert np.array_equal(x2, x) and np.array_equal(y2, 2.0 * y)    # (integral data: exact)
+    np.testing.assert_array_equal(vb2, vbo)
+    certificates(A, b, 2.0 * c, u, tail, head, x2, y2, vb2, cb2)
     # unchanged costs afterwards: the kept path is taken again
-    res3, x3, _, vb3, _ = run(ctx, A, b, c2, u, vb2.astype(np.int8), cb2.astype(np.int8))
+    res3, x3, _, vb3, _ = run(ctx, A, b, 2.0 * c, u, vb2.astype(np.int8), cb2.astype(np.int8))
     assert int(res3.status) == 0 and int(res3.iters) == 0 and int(res3.warm_start_used) == 2
     assert np.array_equal(x3, x2)
+    # cheaper non-tree arcs (capacitated, so they may flip): the run is the oracle's, pivot for pivot
+    c3 = 2.0 * c
+    nontree = np.flatnonzero(vb2[:E] != 0)
+    c3[nontree[::3]] = 1.0
+    res4, x4, y4, vb4, cb4 = run(ctx, A, b, c3, u, vb2.astype(np.int8), cb2.astype(np.int8))
+    want = dual_network_simplex(tail, head, c3, u, b, vb2, root=V)
+    assert int(res4.warm_start_used) == 2                           # tree arcs kept their costs: potentials still valid
+    same_pivots(res4, x4, vb4, want)
+    assert int(res4.iters) > 0
+    assert float(res4.obj) == pytest.approx(highs(A, b, c3, u), rel=1e-9, abs=1e-9)
