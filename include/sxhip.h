@@ -427,6 +427,25 @@ int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *
                 const uint8_t *row_is_lt, const double *x0, const double *y0, int64_t max_iter, double tol, double *x,
                 double *y, sx_pdlp_result *result);
 
+/* ------------------------------------------------------------------ K16f: band LU of a basis
+ * The reference leaves basis factorisations to its solvers (solver_caller/gurobi.py:202-210); the sparse device
+ * crossover (sx_crossover_band_dev) factors its starting basis -- a band matrix in the natural order of a staged
+ * LP once the dense rows are set aside -- with this module (csrc/sx_bandlu.hip).  n x n matrix with kl sub- and ku
+ * super-diagonals given as device triplets (row, column, value: int32, int32, double); LAPACK general-band storage
+ * in HBM ((2 kl + ku + 1) n doubles).  factor: partial pivoting inside the band, panels of 32 columns; a column
+ * whose largest candidate pivot is <= pivot_tol is REPLACED by the unit vector of the row on its diagonal and
+ * reported (replaced_host[n], host, may be NULL; ipiv_host[n] the row swapped with j at step j).  solve: nrhs
+ * right-hand sides, column major with leading dimension ldx, in place; trans 0: A x = b, 1: A^T x = b (A = the
+ * matrix with its replaced columns).  Limits: kl + 32 <= 1536, kl + ku + 32 <= 2400.  Blocking (factor) /
+ * stream-ordered (solve); arrays device unless named host. */
+typedef struct sx_bandlu sx_bandlu;
+int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
+                         const double *val, sx_bandlu **out);
+int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
+                         int32_t *ipiv_host);
+int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
+int sx_bandlu_destroy(sx_bandlu *h);
+
 /* Network simplex (K16n) for the re-solves of the network crossover (network_methods/net_manager.py:211-222
  * solve_subproblem -> solve_mcf / solve_ot with warm_start_basis; the reference hands these to Gurobi's /
  * CPLEX's simplex).  A must be a node-arc incidence matrix -- every column exactly one +1 (tail row) and one

@@ -1,0 +1,578 @@
+// Band LU with partial pivoting on the device (kernel group K16f): the factorisation of the starting basis of
+// the sparse crossover (sx_crossover_band.hip).  The reference leaves every basis factorisation to Gurobi /
+// CPLEX / Mosek (solver_caller/gurobi.py:202-210 model.optimize()); rounds 1-2 kept an explicit dense m x m
+// inverse (8 m^2 bytes: 80 GB at 1e5 rows, installed by m pivots in 47 s).  A staged ("staircase") LP basis in
+// its natural order is a BAND matrix once its few dense rows are set aside, so it is factored as one:
+//
+//   storage   LAPACK general-band layout, column major: AB(kl + ku + i - j, j) = A(i, j), ldab = 2 kl + ku + 1
+//             (the first kl rows of every column are room for the fill partial pivoting creates);
+//   factor    panels of 32 columns.  k_gb_panel: ONE workgroup holds the panel's kl + 32 rows in registers (a row
+//             per lane, 32 doubles), per column: arg-max over the lanes -> row swap through LDS -> scale -> rank-one
+//             update in registers.  k_gb_apply: the columns to the right (<= ku + kl + 32 of them), 8 per workgroup
+//             in LDS: the panel's 32 row swaps, then 32 elimination steps with the multipliers read from L2.
+//             A column without a usable pivot is REPLACED in place by the unit vector of the row on its diagonal
+//             (pivot 1, no multipliers): the caller learns which columns were replaced and treats those rows as
+//             covered by their logical variable -- a singular or ill-conditioned guess of a basis is repaired
+//             instead of failing the factorisation;
+//   solves    the same panel kernels run over a dense right-hand-side block (forward), a mirror pair for U, and
+//             the transposed pair; right-hand sides 8 per workgroup, so hundreds of them cost what one costs.
+//
+// fp64, FMA contraction off like the rest of the library.  No atomics; a fixed arithmetic order per entry.
+#include "sx_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+struct sx_bandlu {
+    sx_ctx *ctx = nullptr;
+    int64_t n = 0;
+    int kl = 0, ku = 0, ldab = 0;
+    double *ab = nullptr;
+    int32_t *ipiv = nullptr;     // [n] global row swapped with j at step j
+    int32_t *replaced = nullptr; // [n] 1: column j was replaced by a unit vector
+    int32_t *err = nullptr;      // [1] scatter found an entry outside the band
+    bool factored = false;
+};
+
+namespace {
+
+constexpr int GB_NB = 32; // panel width
+constexpr int GB_CB = 8;  // target columns per workgroup of the apply / solve kernels
+constexpr int GB_T2 = 256;
+
+__device__ __forceinline__ double &AB(double *ab, int ldab, int kl, int ku, int64_t i, int64_t j) {
+    return ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
+}
+
+__global__ __launch_bounds__(256) void k_gb_scatter(int64_t nnz, const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, double *__restrict__ ab, int ldab, int kl,
+                                                    int ku, int64_t n, int32_t *__restrict__ err) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= nnz) return;
+    const int64_t i = row[t], j = col[t];
+    if (i < 0 || j < 0 || i >= n || j >= n || i - j > kl || j - i > ku) {
+        *err = 1;
+        return;
+    }
+    AB(ab, ldab, kl, ku, i, j) = val[t]; // (duplicates are the caller's business: last writer wins)
+}
+
+// ------------------------------------------------------------------------------------------- panel
+// Rows j0 .. j0 + R - 1 of the panel's columns j0 .. j0 + ncol - 1, a row per lane and slot: lane t holds rows
+// t, t + T, ... (RPT of them).  LDS: the two rows of a swap, the reduction of the arg-max.
+template <int T, int RPT>
+struct GbPanelShared {
+    double sA[GB_NB], sB[GB_NB];
+    double rv[T / 64];
+    int ri[T / 64];
+    int s_p;
+};
+
+// one column step of the panel, C a compile-time constant so that v[][C] stays in registers
+template <int T, int RPT, int C>
+__device__ __forceinline__ void gb_panel_step(double (&v)[RPT][GB_NB], GbPanelShared<T, RPT> &sh, double *__restrict__ ab, int ldab,
+                                              int kl, int ku, int64_t j0, int ncol, int R, double tol,
+                                              int32_t *__restrict__ ipiv, int32_t *__restrict__ replaced) {
+    constexpr int c = C;
+    const int tid = threadIdx.x;
+    if (c >= ncol) return; // uniform
+    // ---- arg-max of |a(rho, c)| over rho in [c, min(c + kl, R - 1)], ties to the smaller row
+    double best = -1.0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rho = tid + k * T;
+        if (rho >= c && rho <= c + kl && rho < R) {
+            const double a = fabs(v[k][c]);
+            if (a > best) {
+                best = a;
+                bi = rho;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        sh.rv[tid >> 6] = best;
+        sh.ri[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double b = sh.rv[0];
+        int i = sh.ri[0];
+        for (int w = 1; w < T / 64; ++w)
+            if (sh.rv[w] > b || (sh.rv[w] == b && sh.ri[w] < i)) {
+                b = sh.rv[w];
+                i = sh.ri[w];
+            }
+        const bool bad = !(b > tol); // (NaN counts as unusable)
+        sh.s_p = bad ? -1 : i;
+        ipiv[j0 + c] = static_cast<int32_t>(j0 + (bad ? c : i));
+        replaced[j0 + c] = bad ? 1 : 0;
+    }
+    __syncthreads();
+    const int p = sh.s_p;
+    if (p < 0) {
+        // no usable pivot: the column becomes the unit vector of the row on its diagonal
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int rho = tid + k * T;
+            v[k][c] = (rho == c) ? 1.0 : 0.0;
+        }
+        // ... including its part above the panel
+        const int64_t j = j0 + c;
+        const int64_t i_lo = (j - ku - kl > 0) ? j - ku - kl : 0;
+        for (int64_t i = i_lo + tid; i < j0; i += T) AB(ab, ldab, kl, ku, i, j) = 0.0;
+        return;
+    }
+    // ---- swap rows c and p in the columns from c on (the multipliers to the left stay where they are:
+    //      LAPACK's band convention -- a row moved down would leave the band), pivot row to every lane
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rho = tid + k * T;
+        if (rho == p) {
+#pragma unroll
+            for (int q = c; q < GB_NB; ++q) sh.sB[q] = v[k][q];
+        }
+        if (rho == c && p != c) {
+#pragma unroll
+            for (int q = c; q < GB_NB; ++q) sh.sA[q] = v[k][q];
+        }
+    }
+    __syncthreads();
+    if (p != c) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int rho = tid + k * T;
+            if (rho == c) {
+#pragma unroll
+                for (int q = c; q < GB_NB; ++q) v[k][q] = sh.sB[q];
+            }
+            if (rho == p) {
+#pragma unroll
+                for (int q = c; q < GB_NB; ++q) v[k][q] = sh.sA[q];
+            }
+        }
+    }
+    const double piv = sh.sB[c];
+    // ---- multipliers and rank-one update of the columns to the right inside the panel
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rho = tid + k * T;
+        if (rho > c && rho <= c + kl && rho < R) {
+            const double l = v[k][c] / piv;
+            v[k][c] = l;
+#pragma unroll
+            for (int q = c + 1; q < GB_NB; ++q) v[k][q] = v[k][q] - l * sh.sB[q];
+        }
+    }
+    __syncthreads(); // sA / sB are rewritten by the next column
+}
+
+template <int T, int RPT, int C>
+struct GbPanelSteps {
+    static __device__ __forceinline__ void run(double (&v)[RPT][GB_NB], GbPanelShared<T, RPT> &sh, double *__restrict__ ab, int ldab,
+                                               int kl, int ku, int64_t j0, int ncol, int R, double tol,
+                                               int32_t *__restrict__ ipiv, int32_t *__restrict__ replaced) {
+        gb_panel_step<T, RPT, C>(v, sh, ab, ldab, kl, ku, j0, ncol, R, tol, ipiv, replaced);
+        GbPanelSteps<T, RPT, C + 1>::run(v, sh, ab, ldab, kl, ku, j0, ncol, R, tol, ipiv, replaced);
+    }
+};
+template <int T, int RPT>
+struct GbPanelSteps<T, RPT, GB_NB> {
+    static __device__ __forceinline__ void run(double (&)[RPT][GB_NB], GbPanelShared<T, RPT> &, double *, int, int, int, int64_t, int,
+                                               int, double, int32_t *, int32_t *) {}
+};
+
+template <int T, int RPT>
+__global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0,
+                                                int ncol, double tol, int32_t *__restrict__ ipiv,
+                                                int32_t *__restrict__ replaced) {
+    __shared__ GbPanelShared<T, RPT> sh;
+    const int tid = threadIdx.x;
+    const int64_t R64 = (n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol;
+    const int R = static_cast<int>(R64);
+    double v[RPT][GB_NB];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rho = tid + k * T;
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) {
+            double x = 0.0;
+            // (i, j) = (j0 + rho, j0 + c) is stored iff  c - ku - kl <= rho <= c + kl
+            if (rho < R && c < ncol && rho <= c + kl && rho >= c - ku - kl) x = AB(ab, ldab, kl, ku, j0 + rho, j0 + c);
+            v[k][c] = x;
+        }
+    }
+    GbPanelSteps<T, RPT, 0>::run(v, sh, ab, ldab, kl, ku, j0, ncol, R, tol, ipiv, replaced);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rho = tid + k * T;
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c)
+            if (rho < R && c < ncol && rho <= c + kl && rho >= c - ku - kl) AB(ab, ldab, kl, ku, j0 + rho, j0 + c) = v[k][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- apply a panel
+// Target: GB_CB columns per workgroup, each a vector indexed by global row.  BAND: columns jt0 + k of the band
+// matrix itself (stored rows [j - ku - kl, j + kl]); otherwise columns of a dense block X (ldx).
+// LDS holds rows j0 .. j0 + R - 1 of the targets; the panel's swaps, then its elimination steps.
+template <bool BAND>
+__global__ __launch_bounds__(GB_T2) void k_gb_apply(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0,
+                                                    int ncol, const int32_t *__restrict__ ipiv, int64_t jt0, int64_t ntgt,
+                                                    double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double w[]; // [R][GB_CB]
+    const int tid = threadIdx.x;
+    const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    // ---- load
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        for (int rho = tid; rho < R; rho += GB_T2) {
+            double x = 0.0;
+            if (t < ntgt) {
+                const int64_t i = j0 + rho;
+                if (BAND) {
+                    const int64_t j = jt0 + t;
+                    if (i >= j - ku - kl && i <= j + kl) x = AB(ab, ldab, kl, ku, i, j);
+                } else {
+                    x = X[i + t * ldx];
+                }
+            }
+            w[rho * GB_CB + k] = x;
+        }
+    }
+    __syncthreads();
+    // ---- column by column: the step's row swap, then its elimination  w[rho] -= L(rho, c) * w[c], rho in (c, c + kl]
+    for (int c = 0; c < ncol; ++c) {
+        const int p = static_cast<int>(ipiv[j0 + c] - j0);
+        if (p != c) { // uniform
+            if (tid < GB_CB) {
+                const double a = w[c * GB_CB + tid];
+                w[c * GB_CB + tid] = w[p * GB_CB + tid];
+                w[p * GB_CB + tid] = a;
+            }
+            __syncthreads();
+        }
+        const int hi = (c + kl < R - 1) ? c + kl : R - 1;
+        double u[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) u[k] = w[c * GB_CB + k];
+        for (int rho = c + 1 + tid; rho <= hi; rho += GB_T2) {
+            const double l = AB(ab, ldab, kl, ku, j0 + rho, j0 + c);
+            if (l != 0.0) {
+#pragma unroll
+                for (int k = 0; k < GB_CB; ++k) w[rho * GB_CB + k] = w[rho * GB_CB + k] - l * u[k];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        if (t >= ntgt) continue;
+        for (int rho = tid; rho < R; rho += GB_T2) {
+            const int64_t i = j0 + rho;
+            if (BAND) {
+                const int64_t j = jt0 + t;
+                if (i >= j - ku - kl && i <= j + kl) AB(ab, ldab, kl, ku, i, j) = w[rho * GB_CB + k];
+            } else {
+                X[i + t * ldx] = w[rho * GB_CB + k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- U x = b (backward)
+// Panel columns j0 .. j0 + ncol - 1, rows i0 = max(0, j0 - ku - kl) .. j0 + ncol - 1 of GB_CB right-hand sides.
+__global__ __launch_bounds__(GB_T2) void k_gb_usolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                     int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X,
+                                                     int64_t ldx) {
+    extern __shared__ double w[];
+    const int tid = threadIdx.x;
+    const int kw = ku + kl;
+    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
+    const int R = static_cast<int>(j0 + ncol - i0);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        for (int rho = tid; rho < R; rho += GB_T2) w[rho * GB_CB + k] = (t < ntgt) ? X[i0 + rho + t * ldx] : 0.0;
+    }
+    __syncthreads();
+    for (int c = ncol - 1; c >= 0; --c) {
+        const int64_t j = j0 + c;
+        const int rj = static_cast<int>(j - i0);
+        const double d = ab[static_cast<size_t>(kl + ku) + static_cast<size_t>(j) * ldab];
+        if (tid < GB_CB) w[rj * GB_CB + tid] = w[rj * GB_CB + tid] / d;
+        __syncthreads();
+        double u[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) u[k] = w[rj * GB_CB + k];
+        const int64_t ilo = (j - kw > i0) ? j - kw : i0;
+        for (int64_t i = ilo + tid; i < j; i += GB_T2) {
+            const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
+            if (a != 0.0) {
+                const int rho = static_cast<int>(i - i0);
+#pragma unroll
+                for (int k = 0; k < GB_CB; ++k) w[rho * GB_CB + k] = w[rho * GB_CB + k] - a * u[k];
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        if (t >= ntgt) continue;
+        for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + t * ldx] = w[rho * GB_CB + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- U^T x = b (forward)
+// x_j = (b_j - sum_{i<j} U(i, j) x_i) / U(j, j): rows i0 .. j0 + ncol - 1 in LDS; per column a dot product over
+// the lanes (32 lanes per right-hand side), reduced through LDS.
+__global__ __launch_bounds__(GB_T2) void k_gb_utsolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                      int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X,
+                                                      int64_t ldx) {
+    extern __shared__ double w[];
+    __shared__ double red[GB_T2];
+    const int tid = threadIdx.x;
+    const int kw = ku + kl;
+    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
+    const int R = static_cast<int>(j0 + ncol - i0);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        for (int rho = tid; rho < R; rho += GB_T2) w[rho * GB_CB + k] = (t < ntgt) ? X[i0 + rho + t * ldx] : 0.0;
+    }
+    __syncthreads();
+    const int k = tid & (GB_CB - 1), lane = tid / GB_CB; // 32 lanes per right-hand side
+    constexpr int LPT = GB_T2 / GB_CB;
+    for (int c = 0; c < ncol; ++c) {
+        const int64_t j = j0 + c;
+        const int64_t ilo = (j - kw > i0) ? j - kw : i0;
+        double s = 0.0;
+        for (int64_t i = ilo + lane; i < j; i += LPT)
+            s += ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] * w[static_cast<int>(i - i0) * GB_CB + k];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < GB_CB) {
+            double acc = 0.0;
+            for (int q = 0; q < LPT; ++q) acc += red[q * GB_CB + tid];
+            const int rj = static_cast<int>(j - i0);
+            w[rj * GB_CB + tid] = (w[rj * GB_CB + tid] - acc) / ab[static_cast<size_t>(kl + ku) + static_cast<size_t>(j) * ldab];
+        }
+        __syncthreads();
+    }
+    for (int kk = 0; kk < GB_CB; ++kk) {
+        const int64_t t = t0 + kk;
+        if (t >= ntgt) continue;
+        for (int rho = static_cast<int>(j0 - i0) + tid; rho < R; rho += GB_T2) X[i0 + rho + t * ldx] = w[rho * GB_CB + kk];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- L^T with swaps (backward)
+// for j descending: x_j -= sum_{i=j+1..j+kl} L(i, j) x_i; swap x_j <-> x_ipiv(j).  Rows j0 .. j0 + R - 1 in LDS.
+__global__ __launch_bounds__(GB_T2) void k_gb_ltsolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                      int64_t j0, int ncol, const int32_t *__restrict__ ipiv, int64_t ntgt,
+                                                      double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double w[];
+    __shared__ double red[GB_T2];
+    const int tid = threadIdx.x;
+    const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        for (int rho = tid; rho < R; rho += GB_T2) w[rho * GB_CB + k] = (t < ntgt) ? X[j0 + rho + t * ldx] : 0.0;
+    }
+    __syncthreads();
+    const int k = tid & (GB_CB - 1), lane = tid / GB_CB;
+    constexpr int LPT = GB_T2 / GB_CB;
+    for (int c = ncol - 1; c >= 0; --c) {
+        const int hi = (c + kl < R - 1) ? c + kl : R - 1;
+        double s = 0.0;
+        for (int rho = c + 1 + lane; rho <= hi; rho += LPT)
+            s += ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] * w[rho * GB_CB + k];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < GB_CB) {
+            double acc = 0.0;
+            for (int q = 0; q < LPT; ++q) acc += red[q * GB_CB + tid];
+            const double xj = w[c * GB_CB + tid] - acc;
+            const int p = static_cast<int>(ipiv[j0 + c] - j0);
+            if (p != c) {
+                w[c * GB_CB + tid] = w[p * GB_CB + tid];
+                w[p * GB_CB + tid] = xj;
+            } else {
+                w[c * GB_CB + tid] = xj;
+            }
+        }
+        __syncthreads();
+    }
+    for (int kk = 0; kk < GB_CB; ++kk) {
+        const int64_t t = t0 + kk;
+        if (t >= ntgt) continue;
+        for (int rho = tid; rho < R; rho += GB_T2) X[j0 + rho + t * ldx] = w[rho * GB_CB + kk];
+    }
+}
+
+} // namespace
+
+SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
+                                const double *val, sx_bandlu **out) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(out && n > 0 && kl >= 0 && ku >= 0 && nnz >= 0, "bad argument");
+    SX_REQUIRE(nnz == 0 || (row && col && val), "NULL triplets");
+    SX_REQUIRE(static_cast<int64_t>(kl) + GB_NB <= 1536, "band too wide for the panel kernel (kl + 32 > 1536 rows)");
+    const size_t lds = static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double);
+    SX_REQUIRE(lds <= 150 * 1024, "band too wide for the solve kernels' LDS block (kl + ku + 32 > 2400 rows)");
+    sx_bandlu *h = new (std::nothrow) sx_bandlu();
+    SX_REQUIRE(h != nullptr, "out of host memory");
+    h->ctx = ctx;
+    h->n = n;
+    h->kl = kl;
+    h->ku = ku;
+    h->ldab = 2 * kl + ku + 1;
+    struct Guard {
+        sx_bandlu *h;
+        ~Guard() {
+            if (h) {
+                (void)hipFree(h->ab);
+                (void)hipFree(h->ipiv);
+                delete h;
+            }
+        }
+    } guard{h};
+    const size_t bytes = sizeof(double) * static_cast<size_t>(h->ldab) * static_cast<size_t>(n);
+    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ab), bytes));
+    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4)));
+    h->replaced = h->ipiv + n;
+    h->err = h->replaced + n;
+    hipStream_t s = ctx->stream;
+    {   // the LDS blocks of the apply / solve kernels pass the 64 KiB a launch gets by default
+        const int cap = 150 * 1024;
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_usolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_utsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_ltsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    }
+    SX_HIP(hipMemsetAsync(h->ab, 0, bytes, s));
+    SX_HIP(hipMemsetAsync(h->ipiv, 0, sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4), s));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_gb_scatter, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0, s, nnz, row, col, val, h->ab,
+                           h->ldab, kl, ku, n, h->err);
+    int32_t err = 0;
+    SX_HIP(hipMemcpyAsync(&err, h->err, sizeof(err), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    SX_HIP(hipGetLastError());
+    SX_REQUIRE(err == 0, "an entry lies outside the band (kl = %d, ku = %d) or outside the matrix", kl, ku);
+    guard.h = nullptr;
+    *out = h;
+    return SX_OK;
+}
+
+SX_API int sx_bandlu_destroy(sx_bandlu *h) {
+    if (!h) return SX_OK;
+    sx_device_guard guard(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    (void)hipFree(h->ab);
+    (void)hipFree(h->ipiv);
+    delete h;
+    return SX_OK;
+}
+
+SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
+                                int32_t *ipiv_host) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_ctx *ctx = h->ctx;
+    SX_ENTER(ctx);
+    SX_REQUIRE(!h->factored, "already factored");
+    hipStream_t s = ctx->stream;
+    const int kl = h->kl, ku = h->ku;
+    const int64_t n = h->n;
+    const int rows = kl + GB_NB; // rows of a panel: a row per lane and register slot
+    for (int64_t j0 = 0; j0 < n; j0 += GB_NB) {
+        const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+        if (rows <= 512)
+            hipLaunchKernelGGL((k_gb_panel<512, 1>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
+                               h->ipiv, h->replaced);
+        else if (rows <= 1024)
+            hipLaunchKernelGGL((k_gb_panel<512, 2>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
+                               h->ipiv, h->replaced);
+        else
+            hipLaunchKernelGGL((k_gb_panel<512, 3>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
+                               h->ipiv, h->replaced);
+        // columns to the right that the panel's rows reach: up to j0 + ncol - 1 + ku + kl
+        const int64_t jt0 = j0 + ncol;
+        const int64_t jt1 = std::min<int64_t>(n, j0 + ncol + ku + kl);
+        const int64_t ntgt = jt1 - jt0;
+        if (ntgt > 0) {
+            const int R = static_cast<int>(std::min<int64_t>(n - j0, static_cast<int64_t>(kl) + ncol));
+            const size_t lds = static_cast<size_t>(R) * GB_CB * sizeof(double);
+            hipLaunchKernelGGL((k_gb_apply<true>), dim3(static_cast<unsigned>((ntgt + GB_CB - 1) / GB_CB)), dim3(GB_T2), lds, s,
+                               h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, jt0, ntgt, nullptr, 0);
+        }
+    }
+    SX_HIP(hipGetLastError());
+    h->factored = true;
+    std::vector<int32_t> rep(static_cast<size_t>(n));
+    SX_HIP(hipMemcpyAsync(rep.data(), h->replaced, sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
+    if (ipiv_host) SX_HIP(hipMemcpyAsync(ipiv_host, h->ipiv, sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipStreamSynchronize(s));
+    int64_t cnt = 0;
+    for (int64_t j = 0; j < n; ++j) cnt += rep[static_cast<size_t>(j)] != 0;
+    if (n_replaced_out) *n_replaced_out = cnt;
+    if (replaced_host) std::memcpy(replaced_host, rep.data(), sizeof(int32_t) * static_cast<size_t>(n));
+    return SX_OK;
+}
+
+// In-place solve of nrhs right-hand sides X (column major, ldx >= n): trans = 0: A x = b, 1: A^T x = b.
+SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_ctx *ctx = h->ctx;
+    SX_ENTER(ctx);
+    SX_REQUIRE(h->factored, "factor first");
+    SX_REQUIRE(X && ldx >= h->n && nrhs >= 0, "bad right-hand side block");
+    if (nrhs == 0) return SX_OK;
+    hipStream_t s = ctx->stream;
+    const int kl = h->kl, ku = h->ku;
+    const int64_t n = h->n;
+    const unsigned grid = static_cast<unsigned>((nrhs + GB_CB - 1) / GB_CB);
+    const int64_t npanel = (n + GB_NB - 1) / GB_NB;
+    const size_t lds_l = static_cast<size_t>(kl + GB_NB) * GB_CB * sizeof(double);
+    const size_t lds_u = static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double);
+    if (!trans) {
+        for (int64_t p = 0; p < npanel; ++p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+            hipLaunchKernelGGL((k_gb_apply<false>), dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv,
+                               0, nrhs, X, ldx);
+        }
+        for (int64_t p = npanel - 1; p >= 0; --p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+            hipLaunchKernelGGL(k_gb_usolve, dim3(grid), dim3(GB_T2), lds_u, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+        }
+    } else {
+        for (int64_t p = 0; p < npanel; ++p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+            hipLaunchKernelGGL(k_gb_utsolve, dim3(grid), dim3(GB_T2), lds_u, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+        }
+        for (int64_t p = npanel - 1; p >= 0; --p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+            hipLaunchKernelGGL(k_gb_ltsolve, dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, nrhs, X,
+                               ldx);
+        }
+    }
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}

@@ -321,6 +321,32 @@ class Context:
         return float(rec.min_rc), int(rec.argmin), int(rec.n_violating)
 
 
+class BandLU:
+    """K16f: band LU with partial pivoting of an n x n matrix given as device triplets (sx_bandlu_*)."""
+
+    def __init__(self, ctx: "Context", n: int, kl: int, ku: int, row: "DeviceArray", col: "DeviceArray", val: "DeviceArray"):
+        self.ctx, self.n, self.kl, self.ku = ctx, int(n), int(kl), int(ku)
+        h = C.c_void_p()
+        _l.check(ctx._lib.sx_bandlu_create_dev(ctx.handle, int(n), int(kl), int(ku), int(val.size), row.ptr, col.ptr, val.ptr,
+                                               C.byref(h)))
+        self.handle = h
+
+    def factor(self, pivot_tol: float = 1e-11):
+        """-> (replaced[n] int32: column became a unit vector, ipiv[n] int32: row swapped with j at step j)."""
+        cnt = C.c_int64(0)
+        rep, piv = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        _l.check(self.ctx._lib.sx_bandlu_factor_dev(self.handle, float(pivot_tol), C.byref(cnt), rep.ctypes.data, piv.ctypes.data))
+        return rep, piv
+
+    def solve(self, X: "DeviceArray", nrhs: int = 1, ldx: Optional[int] = None, trans: bool = False) -> None:
+        _l.check(self.ctx._lib.sx_bandlu_solve_dev(self.handle, int(bool(trans)), int(nrhs), X.ptr, int(ldx or self.n)))
+
+    def free(self) -> None:
+        if self.handle is not None:
+            self.ctx._lib.sx_bandlu_destroy(self.handle)
+            self.handle = None
+
+
 class DeviceArray:
     """A typed, contiguous vector in HBM."""
 

