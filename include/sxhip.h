@@ -446,6 +446,21 @@ int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out
 int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
 int sx_bandlu_destroy(sx_bandlu *h);
 
+/* Sparse crossover (K16s, csrc/sx_crossover_band.hip): the same job as sx_simplex_crossover_dev -- from the point
+ * x_start[n] (what sx_pdlp_dev leaves: columns at a bound exactly where the projection put them) to an optimal
+ * vertex and its basis -- without the dense m x m inverse: the starting basis is chosen by position (rows in their
+ * natural order, dense rows covered by their logicals), its band part factored once (K16f), and the simplex works
+ * on an explicit tableau of the columns that can still move (superbasic ones + what pricing adds), every entering
+ * column kept as an eta vector for duals and new columns.  Memory O(nnz + m (kl + ku) + m |tracked|).  Replaces
+ * the crossover the reference's backends run behind their barrier (lp_methods/algorithms.py:50-54 ->
+ * solver_caller/gurobi.py:111-115).  Returns SX_ERR_UNSUPPORTED when the basis is not a band matrix in the natural
+ * row order (the caller then takes sx_simplex_crossover_dev).  Outputs and result as sx_simplex_crossover_dev;
+ * result->phase1_iters counts the columns pricing added to the tableau.  Blocking; arrays device. */
+int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                          const double *u, const uint8_t *row_is_lt, const double *x_start, int64_t max_iter,
+                          double feas_tol, double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
+                          sx_simplex_result *result);
+
 /* Network simplex (K16n) for the re-solves of the network crossover (network_methods/net_manager.py:211-222
  * solve_subproblem -> solve_mcf / solve_ot with warm_start_basis; the reference hands these to Gurobi's /
  * CPLEX's simplex).  A must be a node-arc incidence matrix -- every column exactly one +1 (tail row) and one

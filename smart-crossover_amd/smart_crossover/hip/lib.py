@@ -130,6 +130,8 @@ PROTOTYPES = {
     "sx_simplex_crossover_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                         C.POINTER(SimplexResult)]),
     "sx_pdlp_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp, C.POINTER(PdlpResult)]),
+    "sx_crossover_band_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                     C.POINTER(SimplexResult)]),
     "sx_bandlu_create_dev": (_int, [_vp, _i64, _int, _int, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "sx_bandlu_factor_dev": (_int, [_vp, _dbl, C.POINTER(_i64), _vp, _vp]),
     "sx_bandlu_solve_dev": (_int, [_vp, _int, _i64, _vp, _i64]),

@@ -38,6 +38,9 @@ _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
 PDLP_ITERS = 20000       # first-order stage in front of the crossover ('barrier' runs): iteration limit (0: skip it)
 PDLP_TOL = 1e-9          # ... and its relative KKT tolerance
+BAND_MIN_ROWS = 30000    # from this many rows on the crossover behind the first-order stage is the sparse one (K16s:
+                         # band LU of the starting basis + tableau of the tracked columns) when the basis has that
+                         # structure; below, the dense inverse of K16 (8 m^2 bytes) is cheaper to set up
 NETDUAL_FEAS_TOL = 1e-9  # bound violation of a tree arc the dual network simplex still calls feasible
 CRASH_MARGIN = 1e-6      # a column this far (relative) inside its bounds / a slack this large counts as basic
 
@@ -167,6 +170,7 @@ class HipCaller(SolverCaller):
         d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
         d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
         vb_in = cb_in = x_start = None
+        self._res = None
         t0 = time.perf_counter()
         d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
         self.pdlp = None
@@ -183,7 +187,16 @@ class HipCaller(SolverCaller):
                                      float(os.environ.get("SX_PDLP_TOL", PDLP_TOL)), d_px, d_py)
                 self._warm_point = (d_px.download(), d_py.download())
                 self.pdlp_seconds = time.perf_counter() - t0
-            self._warm = self._crash_basis(ctx, dA)
+                mode = os.environ.get("SX_LP_CROSSOVER", "auto")
+                if mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS):
+                    try:
+                        self._res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_px, 0, 1e-7,
+                                                       float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
+                        self.solved_by = "crossover_band"
+                    except NotImplementedError:
+                        self._res = None          # no band structure: the dense crossover below
+            if self._res is None:
+                self._warm = self._crash_basis(ctx, dA)
             if self._warm is not None:          # crossover: start AT the interior point (superbasic columns)
                 x_start = ctx.to_device(np.ascontiguousarray(self._warm_point[0], dtype=np.float64))
         if self._warm is not None and self._warm.vbasis.size == n and self._warm.cbasis.size == m:
@@ -195,9 +208,9 @@ class HipCaller(SolverCaller):
             if getattr(holder, "session", None) is None:
                 holder.session = ctx.simplex_session()
             session = holder.session
-        self._res = None
-        self.solved_by = "simplex"
-        if self._network and vb_in is not None and x_start is None and not self._row_lt.any():
+        if self._res is None:
+            self.solved_by = "simplex"
+        if self._res is None and self._network and vb_in is not None and x_start is None and not self._row_lt.any():
             # a network sub-problem with a warm tree basis.  First the dual method on the whole GPU (K16d: the
             # tree need not be primal feasible, new arcs at the wrong bound are flipped); status 5 = outside its
             # domain (an uncapacitated arc would have to flip, A is no incidence matrix, not a tree).  Then the

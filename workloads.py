@@ -418,34 +418,56 @@ def lp_shard(rank: int, world: int, m: int = 1_000_000, n_block: int = 10_000_00
 # --------------------------------------------------------------------------
 # N1: the configuration BASELINE.json's metric is quoted on ("1e6-variable netlib-style LP")
 # --------------------------------------------------------------------------
-def netlib_lp(m: int = 100_000, n: int = 1_000_000, seed: int = 6, window: int = 512,
+def netlib_lp(m: int = 100_000, n: int = 1_000_000, seed: int = 6, window: int = 48,
               frac_lt: float = 0.5, frac_upper: float = 0.25, name: Optional[str] = None) -> LPInstance:
     """A *consistent* netlib-style (staircase + linking rows) LP with a synthetic late-barrier iterate.
 
-    Structure as in ``_staircase_blocks`` (8 entries per column: six in a window of ``window`` stage rows
-    at the column's home position, one in the following window, one in a linking row; 1 % of the rows are
-    linking rows; home positions grow with the column index), vectors as in ``sparse_lp`` -- so, unlike
-    ``lp_shard`` (a kernel workload whose senses are drawn independently of its slacks), (x, y) here IS a
-    strictly complementary primal-dual pair of the LP to 1e-9: b = A x + slack with slack > 0 only on '<'
-    rows whose dual is ~0, c = A^T y + s_d with s_d ~ 1e-10 on the ~m "basic" columns.  The basic columns
-    are one of every n/m consecutive columns (random offset), so every stretch of stage rows keeps its
-    share of them and the restricted sub-problem the crossover builds stays feasible."""
+    Structure: 1 % of the rows are linking rows (at the head of the row range), the others stage rows in time
+    order.  Every column is an *activity with a balance row of its own*: one entry of magnitude 0.8..1.2 there,
+    seven of magnitude <= 0.15 elsewhere -- five in the stage rows within ``window``/2 of its own row, one in the
+    following stage (``window``..2 ``window`` rows ahead) and one in a linking row; 1 % of the columns are linking
+    activities (own row a linking row, the small entries in a window of stage rows).  Columns are in the order
+    of their own rows (n/m columns per row), so neighbouring columns touch neighbouring rows, as in multi-period
+    production / inventory models.  Vectors as in ``sparse_lp`` -- unlike ``lp_shard`` (a kernel workload whose
+    senses are drawn independently of its slacks), (x, y) here IS a strictly complementary primal-dual pair of
+    the LP to 1e-9: b = A x + slack with slack > 0 only on '<' rows whose dual is ~0, c = A^T y + s_d with
+    s_d ~ 1e-10 on the m "basic" columns, ONE PER ROW (a random one of the columns that own the row).
+
+    Why own rows: a band matrix with independent U(-1, 1) entries -- the first version of this generator -- has
+    bases whose condition number grows exponentially with rows / bandwidth (products of random matrices; 1e29
+    at 1e4 rows measured), and so do bases in which many columns share their large entry's row: no solver's
+    territory and no netlib model's.  With one basic activity per balance row every basis the crossover can meet
+    is column-dominant after a permutation."""
     rng = np.random.default_rng(seed)
-    nl = max(1, m // 100)                       # linking rows, at the head of the row range
+    nl = max(1, m // 100)                       # linking rows
     ms = m - nl
-    W = max(12, min(window, ms // 4))
-    ws = W // 6
-    j = np.arange(n, dtype=np.int64)
-    home = (j * (ms - 2 * W) // n).astype(np.int64)
-    idx = np.empty((n, 8), dtype=np.int32)
-    val = rng.uniform(-1.0, 1.0, size=(n, 8))
-    val[np.abs(val) < 1e-3] = 0.5
-    idx[:, 0] = rng.integers(0, nl, size=n)
-    for t in range(6):
-        idx[:, 1 + t] = nl + home + t * ws + rng.integers(0, ws, size=n)
-    idx[:, 7] = nl + home + W + rng.integers(0, W, size=n)
-    colptr = np.arange(n + 1, dtype=np.int64) * 8
-    A = sp.csc_matrix((val.ravel(), idx.ravel(), colptr), shape=(m, n)).tocsr()
+    W = max(12, min(window, ms // 8))
+    link_col = (np.arange(n) % 100) == 0        # linking activities, spread over the column range
+    n_link = int(link_col.sum())
+    n_stage = n - n_link
+    own = np.empty(n, dtype=np.int64)
+    own[~link_col] = nl + (np.arange(n_stage, dtype=np.int64) * ms) // n_stage
+    own[link_col] = (np.arange(n_link, dtype=np.int64) * nl) // n_link
+    # where the small entries go: a centre in the stage rows (the own row, or for linking activities the
+    # position of the column in the column range)
+    centre = own.copy()
+    centre[link_col] = nl + (np.flatnonzero(link_col).astype(np.int64) * ms) // n
+    h = W // 2
+    idx = np.empty((n, 8), dtype=np.int64)
+    val = rng.uniform(-0.15, 0.15, size=(n, 8))
+    val[np.abs(val) < 1e-3] = 0.05
+    idx[:, 0] = own
+    val[:, 0] = rng.uniform(0.8, 1.2, size=n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    q = max(1, h // 3)
+    for t, (lo, hi) in enumerate([(-h, -h + q), (-h + q, -1), (1, q + 1), (q + 1, 2 * q + 1), (2 * q + 1, h + 1)]):
+        hi = max(hi, lo + 1)
+        idx[:, 1 + t] = centre + rng.integers(lo, hi, size=n)
+    idx[:, 6] = centre + W + rng.integers(0, W, size=n)
+    idx[:, 7] = rng.integers(0, nl, size=n)
+    stage_part = idx[:, 1:7]
+    np.clip(stage_part, nl, m - 1, out=stage_part)
+    colidx = np.repeat(np.arange(n, dtype=np.int64), 8)
+    A = sp.coo_matrix((val.ravel(), (idx.ravel(), colidx)), shape=(m, n)).tocsr()   # (duplicates are summed)
     A.sort_indices()
 
     y = rng.standard_normal(m)
@@ -456,10 +478,14 @@ def netlib_lp(m: int = 100_000, n: int = 1_000_000, seed: int = 6, window: int =
     u = np.full(n, np.inf)
     has_up = rng.random(n) < frac_upper
     u[has_up] = rng.uniform(1.0, 10.0, int(has_up.sum()))
-    group = max(1, n // m)
+    # one basic column per row: a random one of the row's own columns
+    order = np.argsort(own, kind="stable")
+    first = np.searchsorted(own[order], np.arange(m), side="left")
+    count = np.searchsorted(own[order], np.arange(m), side="right") - first
+    if np.any(count == 0):
+        raise ValueError("netlib_lp needs at least one column per row (n >= 100 m / 99)")
     basic = np.zeros(n, dtype=bool)
-    starts = np.arange(0, n - group + 1, group, dtype=np.int64)
-    basic[starts + rng.integers(0, group, size=starts.size)] = True
+    basic[order[first + (rng.random(m) * count).astype(np.int64)]] = True
     x = np.full(n, 1e-9)
     x[basic] = rng.uniform(0.1, 1.0, int(basic.sum()))
     at_up = (~basic) & has_up & (rng.random(n) < 0.5)
