@@ -188,7 +188,7 @@ class HipCaller(SolverCaller):
                 self._warm_point = (d_px.download(), d_py.download())
                 self.pdlp_seconds = time.perf_counter() - t0
                 mode = os.environ.get("SX_LP_CROSSOVER", "auto")
-                if mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS):
+                if mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS):      # ("dense": K16 whatever the size)
                     try:
                         self._res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_px, 0, 1e-7,
                                                        float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)

@@ -1,0 +1,123 @@
+"""GPU: the sparse crossover (K16s, csrc/sx_crossover_band.hip: position matching + band LU + tableau of the tracked
+columns) behind the first-order stage (K16p) -- the re-solve of the perturbed sub-problem
+(reference lp_methods/algorithms.py:50-54: barrier + crossover inside Gurobi, parity unpinned).  Checked the way
+tests/test_gpu_full_size.py checks the dense crossover: HiGHS' optimal value where HiGHS is quick, and
+solver-independent certificates everywhere (primal / dual feasibility by basis status at the reference's
+tolerances, |B| = m, the reference's own gap test at 1e-8)."""
+import io
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from smart_crossover.hip import default_context
+    return default_context()
+
+
+def perturbed_sub_problem(inst):
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    with redirect_stdout(io.StringIO()):
+        mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+    return lp, mgr
+
+
+def resolve(mgr, inst, monkeypatch, mode):
+    from smart_crossover.solver_caller import solving
+    from smart_crossover.solver_caller.caller import SolverSettings
+    monkeypatch.setenv("SX_LP_CROSSOVER", mode)
+    caller = solving.generate_solver_caller("HIP", SolverSettings(presolve="on", log_console=0))
+    caller.read_genlp(mgr.lp_sub)
+    caller.add_warm_start_solution((mgr.get_subx(inst.x), inst.y))
+    with redirect_stdout(io.StringIO()):
+        caller.run_barrier()
+        out = caller.return_output()
+    return caller, out
+
+
+def certificates(sub, out, tol=1e-6):
+    m, n = sub.A.shape
+    x, y, vb, cb = out.x, out.y, out.basis.vbasis, out.basis.cbasis
+    s_p = sub.b - sub.A @ x
+    lt = np.asarray(sub.sense) == "<"
+    assert np.all(np.abs(s_p[~lt]) <= tol) and np.all(s_p[lt] >= -tol)
+    assert np.all(x >= sub.l - tol) and np.all(x <= sub.u + tol)
+    rc = sub.c - sub.A.T @ y
+    assert np.all(rc[vb == -1] >= -tol) and np.all(rc[vb == -2] <= tol) and np.all(np.abs(rc[vb == 0]) <= tol)
+    assert np.all(y[lt & (cb == -1)] <= tol) and np.all(np.abs(y[cb == 0]) <= tol)
+    assert int(np.count_nonzero(vb == 0) + np.count_nonzero(cb == 0)) == m
+    assert not np.any(vb == -3)
+    assert np.all(x[vb == -1] == sub.l[vb == -1]) and np.all(x[vb == -2] == sub.u[vb == -2])   # non-basic: AT the bound
+
+
+@pytest.mark.parametrize("m,n,seed", [(300, 3000, 1), (3000, 30000, 2), (20000, 200000, 3)])
+def test_band_crossover_reaches_the_vertex(ctx, monkeypatch, m, n, seed):
+    from smart_crossover.lp_methods import algorithms as alg
+    inst = workloads.netlib_lp(m, n, seed=seed)
+    lp, mgr = perturbed_sub_problem(inst)
+    caller, out = resolve(mgr, inst, monkeypatch, "band")
+    assert caller.solved_by == "crossover_band" and out.status == "OPTIMAL"
+    certificates(mgr.lp_sub, out)
+    with redirect_stdout(io.StringIO()):
+        assert alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x)) is True   # gap < 1e-8
+    if m <= 3000:
+        sub = mgr.lp_sub
+        lt = np.asarray(sub.sense) == "<"
+        ref = linprog(sub.c, A_ub=sub.A[lt], b_ub=sub.b[lt], A_eq=sub.A[~lt], b_eq=sub.b[~lt], bounds=np.c_[sub.l, sub.u],
+                      method="highs")
+        assert ref.status == 0
+        assert float(sub.c @ out.x) == pytest.approx(ref.fun, rel=1e-8, abs=1e-9)
+        # the perturbed LP has ONE optimal vertex: same point, hence the same basic set where it is non-degenerate
+        np.testing.assert_allclose(out.x, ref.x, rtol=1e-6, atol=1e-7)
+
+
+def test_band_and_dense_crossover_agree(ctx, monkeypatch):
+    inst = workloads.netlib_lp(1500, 15000, seed=5)
+    lp, mgr = perturbed_sub_problem(inst)
+    c1, o1 = resolve(mgr, inst, monkeypatch, "band")
+    c2, o2 = resolve(mgr, inst, monkeypatch, "dense")
+    assert c1.solved_by == "crossover_band" and c2.solved_by == "simplex"
+    assert o1.status == o2.status == "OPTIMAL"
+    np.testing.assert_allclose(o1.x, o2.x, rtol=1e-7, atol=1e-8)
+    assert np.array_equal(o1.basis.vbasis == 0, o2.basis.vbasis == 0) or float(mgr.lp_sub.c @ o1.x) == pytest.approx(
+        float(mgr.lp_sub.c @ o2.x), rel=1e-10)
+
+
+def test_unstructured_basis_is_refused_and_the_caller_falls_back(ctx, monkeypatch):
+    """A random sparse LP has no band structure in its natural order: SX_ERR_UNSUPPORTED from the sparse crossover,
+    and the 'HIP' backend then runs the dense one."""
+    inst = workloads.sparse_lp(2000, 8000, 6, seed=9, stratified=True)
+    lp, mgr = perturbed_sub_problem(inst)
+    sub = mgr.lp_sub
+    dA = ctx.matrix(sub.A)
+    put = lambda v, t=np.float64: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    with pytest.raises(NotImplementedError):
+        ctx.crossover_band(dA, put(sub.b), put(sub.c), put(sub.l), put(sub.u), put(np.asarray(sub.sense) == "<", np.uint8),
+                           put(mgr.get_subx(inst.x)))
+    dA.free()
+    caller, out = resolve(mgr, inst, monkeypatch, "band")
+    assert caller.solved_by == "simplex" and out.status == "OPTIMAL"
+    certificates(sub, out)
+
+
+def test_headline_size_1e6_variables(ctx, monkeypatch):
+    """The configuration BASELINE.json's metric is quoted on: a 1e6-variable netlib-style LP (1e5 rows), interior point
+    to optimal vertex + basis of the perturbed 1e5 x 1e5 sub-problem, all on the GPU."""
+    from smart_crossover.lp_methods import algorithms as alg
+    inst = workloads.netlib_lp()
+    lp, mgr = perturbed_sub_problem(inst)
+    assert mgr.lp_sub.A.shape[0] == 100_000
+    caller, out = resolve(mgr, inst, monkeypatch, "auto")
+    assert caller.solved_by == "crossover_band" and out.status == "OPTIMAL"
+    certificates(mgr.lp_sub, out)
+    with redirect_stdout(io.StringIO()):
+        assert alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x)) is True
