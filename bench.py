@@ -122,6 +122,17 @@ def crossover_lp_end_to_end(highs_limit_s: float):
                        "sub-problem, host memory to host memory",
            "gpu_ms": (t2 - t0) * 1e3, "gpu_get_perturb_problem_ms": (t1 - t0) * 1e3, "gpu_resolve_ms": (t2 - t1) * 1e3,
            "simplex_pivots": int(out.iter_count), "gap_test_passed": True}
+    if highs_limit_s <= 0:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "lp_c2_highs.json")), reverse=True):
+            cpu = json.load(open(path))
+            cpu["recorded_in"] = os.path.relpath(path, ROOT) + " (python bench.py --highs-seconds SECONDS re-measures it)"
+            rec["cpu"] = cpu
+            if cpu.get("cpu_resolve_status") == "OPTIMAL":
+                rec["speedup_resolve"] = cpu["cpu_resolve_s"] * 1e3 / rec["gpu_resolve_ms"]
+            else:
+                rec["speedup_resolve_at_least"] = cpu["cpu_resolve_s"] * 1e3 / rec["gpu_resolve_ms"]
+            break
     if highs_limit_s > 0:
         t0 = time.perf_counter()
         status = "TIME_LIMIT"
@@ -140,6 +151,99 @@ def crossover_lp_end_to_end(highs_limit_s: float):
                     "cpu_resolve_time_limit_s": highs_limit_s,
                     "speedup_resolve": (secs * 1e3 / rec["gpu_resolve_ms"]) if solved else None,
                     "speedup_resolve_at_least": None if solved else secs * 1e3 / rec["gpu_resolve_ms"]})
+    return rec
+
+
+def _cpu_crossover_lp(inst, highs_limit_s: float):
+    """The CPU path of an LP crossover, timed to completion: the host arithmetic of get_perturb_problem by the
+    numpy/scipy oracle (matrix-free CG) + the re-solve of the perturbed sub-problem by HiGHS (scipy's build; the
+    stand-in for the reference's Gurobi call, lp_methods/algorithms.py:50-54)."""
+    from scipy.optimize import linprog
+    from oracle import lp_path as L         # checker / baseline only
+    t0 = time.perf_counter()
+    res = L.scoring_pass(inst.A, inst.b, inst.c, inst.l, inst.u, inst.x, inst.y)
+    c_pt, _ = L.perturbed_cost_full(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense, inst.x, False, explicit=False)
+    sub = L.sub_problem(inst.A, inst.b, c_pt, inst.l, inst.u, inst.sense, res["fix_low"], res["fix_up"], res["fixed_rows"])
+    t1 = time.perf_counter()
+    lt = np.asarray(sub["sense"]) == "<"
+    A = sub["A"].tocsr()
+    ref = linprog(sub["c"], A_ub=A[lt], b_ub=sub["b"][lt], A_eq=A[~lt], b_eq=sub["b"][~lt], bounds=np.c_[sub["l"], sub["u"]],
+                  method="highs", options={"time_limit": float(highs_limit_s)})
+    t2 = time.perf_counter()
+    return {"cpu_kind": "port (numpy/scipy oracle, matrix-free CG) + HiGHS (scipy's bundled build, method 'highs') on the same "
+                        "sub-problem; the reference would call Gurobi there",
+            "cpu_host_arithmetic_s": t1 - t0, "cpu_resolve_s": t2 - t1, "cpu_total_s": t2 - t0,
+            "cpu_resolve_status": "OPTIMAL" if ref.status == 0 else ("TIME_LIMIT" if ref.status == 1 else f"status {ref.status}"),
+            "cpu_resolve_iterations": int(getattr(ref, "nit", 0) or 0), "cpu_objective": float(ref.fun) if ref.status == 0 else None,
+            "cpu_cores": os.cpu_count(), "cpu_time_limit_s": float(highs_limit_s)}
+
+
+def crossover_lp_1e6(lp_highs_s: float):
+    """BASELINE metric 'crossover wall-time (ms)' on the configuration it is quoted on: a 1e6-variable netlib-style LP
+    (workloads.netlib_lp: 1e5 rows, 8e6 entries, staircase + linking rows), from the interior point (x, y) in host
+    memory to the optimal vertex of the perturbed sub-problem and its basis in host memory -- get_perturb_problem
+    (K1-K6) + the re-solve (reference lp_methods/algorithms.py:45-61: first-order stage K16p + sparse crossover
+    K16s/K16f) + the reference's gap test (:63).  Warm process: the second of two calls is reported (the first
+    also pays the upload of the matrix and the first-use set-up of the kernels).  CPU path beside it: timed in this
+    run with ``--lp-highs SECONDS`` (written to gpurun_out/lp_1e6_highs.json), otherwise the record committed under
+    profiles/ (where and how it was measured is in the record)."""
+    import io
+    from contextlib import redirect_stdout
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    from smart_crossover.solver_caller.caller import SolverSettings
+    from smart_crossover.solver_caller import solving
+    inst = workloads.netlib_lp()
+    runs = []
+    for rep in range(2):
+        lp = GeneralLP(inst.A, inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
+        t0 = time.perf_counter()
+        with redirect_stdout(io.StringIO()):
+            mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+            t1 = time.perf_counter()
+            caller = solving.generate_solver_caller("HIP", SolverSettings(presolve="on", log_console=0))
+            caller.read_genlp(mgr.lp_sub)
+            caller.add_warm_start_solution((mgr.get_subx(inst.x), inst.y))
+            caller.run_barrier()
+            out = caller.return_output()
+            ok = alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x))
+        t2 = time.perf_counter()
+        if out.status != "OPTIMAL" or not ok:
+            raise SystemExit("bench: the device crossover of the 1e6-variable LP did not reach an optimal vertex")
+        runs.append((t2 - t0, t1 - t0, t2 - t1, caller, out, mgr))
+    tot, tgp, trs, caller, out, mgr = runs[1]
+    p = caller.pdlp
+    rec = {"workload": "netlib_lp: 1e5 rows x 1e6 columns, 8e6 entries (staircase + 1 % linking rows); interior point -> optimal "
+                       "vertex + basis of the perturbed sub-problem, host memory to host memory",
+           "sub_problem_shape": list(mgr.lp_sub.A.shape), "gpu_ms": tot * 1e3, "gpu_ms_first_call": runs[0][0] * 1e3,
+           "gpu_get_perturb_problem_ms": tgp * 1e3, "gpu_resolve_ms": trs * 1e3,
+           "first_order_stage": {"iterations": int(p.iters), "restarts": int(p.restarts), "seconds": caller.pdlp_seconds,
+                                 "us_per_iteration": caller.pdlp_seconds / max(int(p.iters), 1) * 1e6,
+                                 "primal_residual": p.primal_residual, "dual_residual": p.dual_residual, "gap": p.gap},
+           "crossover": {"kind": caller.solved_by, "simplex_iterations": int(out.iter_count)},
+           "objective": float(mgr.lp_sub.c @ out.x), "gap_test_passed": True}
+    cpu = None
+    if lp_highs_s > 0:
+        cpu = _cpu_crossover_lp(inst, lp_highs_s)
+        cpu["measured"] = "in this run, on this host"
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(cpu, open(os.path.join(ROOT, "gpurun_out", "lp_1e6_highs.json"), "w"), indent=1)
+    else:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "lp_1e6_highs.json")), reverse=True):
+            cpu = json.load(open(path))
+            cpu["recorded_in"] = os.path.relpath(path, ROOT) + " (python bench.py --lp-highs SECONDS re-measures it)"
+            break
+    if cpu is not None:
+        rec["cpu"] = cpu
+        if cpu.get("cpu_resolve_status") == "OPTIMAL":
+            if abs(cpu["cpu_objective"] - rec["objective"]) > 1e-7 * (1 + abs(rec["objective"])):
+                raise SystemExit("bench: the device's optimum of the 1e6-variable LP differs from HiGHS'")
+            rec["speedup_total"] = cpu["cpu_total_s"] * 1e3 / rec["gpu_ms"]
+            rec["speedup_resolve"] = cpu["cpu_resolve_s"] * 1e3 / rec["gpu_resolve_ms"]
+        else:
+            rec["speedup_total_at_least"] = cpu["cpu_total_s"] * 1e3 / rec["gpu_ms"]
+        rec["target"] = ">= 5x lower crossover wall-time than the CPU path (BASELINE.json)"
     return rec
 
 
@@ -294,8 +398,12 @@ def main():
     ap.add_argument("--c4-highs", action="store_true",
                     help="time config 4's network crossover with the re-solves in HiGHS too (94 s on the box's host cores; "
                          "without it the line quotes profiles/r02/netdual_c4_highs.jsonl)")
-    ap.add_argument("--highs-seconds", type=float, default=120.0,
-                    help="time limit of the HiGHS re-solve timed beside the device crossover of config 2 (0: skip)")
+    ap.add_argument("--highs-seconds", type=float, default=0.0,
+                    help="time the HiGHS re-solve of config 2's sub-problem in this run, with this time limit (0: quote the "
+                         "record under profiles/)")
+    ap.add_argument("--lp-highs", type=float, default=0.0,
+                    help="time the CPU path of the 1e6-variable LP crossover (oracle + HiGHS, this time limit in seconds) in "
+                         "this run and write gpurun_out/lp_1e6_highs.json (0: quote the record under profiles/)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -616,7 +724,8 @@ def main():
                 net_c4["recorded_in"] = "profiles/r02/netdual_c4_highs.jsonl (python bench.py --c4-highs re-measures it)"
                 if abs(rec["cost"] - net_c4["optimal_cost"]) > 1e-9 * (1 + abs(rec["cost"])):
                     raise SystemExit("bench: the device's config-4 optimum differs from the recorded HiGHS optimum")
-        crossover = {"lp_c2_host_path": crossover_host_path(args.cpu_seconds),
+        crossover = {"lp_1e6_end_to_end": crossover_lp_1e6(args.lp_highs),
+                     "lp_c2_host_path": crossover_host_path(args.cpu_seconds),
                      "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
                      "lp_c5_get_perturb_problem": crossover_lp_c5(),
                      "network_c3": net_c3,

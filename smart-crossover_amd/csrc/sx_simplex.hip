@@ -48,7 +48,6 @@
 // this file implements the single-device solver.
 #include "sx_internal.h"
 
-#include <rocblas/rocblas.h>
 #include "sx_segwalk.h"
 
 #include <chrono>
@@ -66,7 +65,6 @@ constexpr double PIV_TOL = 1e-9; // smallest |pivot| accepted
 constexpr int BLAND_AFTER = 100;
 constexpr int SPX_DEFER = 64;    // pivots whose inverse updates are held back and folded in together: the fold moves
                                  // 16 m^2 bytes, 46 % of a pivot at m = 2e4 with a batch of 32
-constexpr int SPX_BLAS_MIN_M = 8192; // from this many rows on a batch is folded in by the library DGEMM (fp64 MFMA)
 constexpr int SPX_REG = 32;      // of the pending columns, those a lane requests before the entering column is known
 
 // ST_FREE: non-basic and not at a bound -- a free variable at 0, or a *superbasic* one at the interior value
@@ -785,18 +783,87 @@ __global__ __launch_bounds__(SX_WG) void k_spx_fold_mask(Spx P, int cnt) {
     }
 }
 
-rocblas_handle spx_blas(int device, hipStream_t s) { // one handle per device, made on first use
-    static rocblas_handle handles[64] = {};
-    if (device < 0 || device >= 64) return nullptr;
-    if (!handles[device]) {
-        if (rocblas_create_handle(&handles[device]) != rocblas_status_success) {
-            handles[device] = nullptr;
-            return nullptr;
+// The rank-64 update itself on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), hand-written: Binv is column major,
+// so the tile is computed TRANSPOSED -- D[kk][ii] = sum_s R[k0 + kk][s] E[i0 + ii][s] -- which puts the index that is
+// contiguous in memory (the row i of Binv) on the MFMA's lane-minor axis: every load and store of the accumulator
+// is four whole 128-byte lines (C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg).  A wave owns 16 columns
+// x 64 rows of Binv (four tiles that share the R fragment, 16 k-steps each): 16 KB of Binv in and out against
+// 10 KB of E / R fragments, which come from L2 -- workgroups are numbered so that the ~1000 that run together
+// cover 64 column tiles x 16 row chunks, i.e. 0.5 MB of R and 2 MB of E per XCD's L2.  The update is memory bound
+// (16 m^2 bytes) with the matrix pipe at about half load (2 m^2 64 flop at 78 TFLOP/s); results differ from the
+// scalar kernel's by the order of the 64 products inside a tile row (the MFMA's own), within the tests' tolerance.
+// NOT the default: see the measurement where it is selected.
+typedef double spx_v4d __attribute__((ext_vector_type(4)));
+constexpr int FM_KT = 64, FM_IC = 16; // column tiles x row chunks of one super-block of workgroups
+
+typedef double spx_v2d __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(SX_WG) void k_spx_fold_mfma(Spx P, int64_t nkt, int64_t nic) {
+    const int64_t m = P.m;
+    // workgroup -> (column tile kt, row chunk ic): super-blocks of FM_KT x FM_IC, column tiles fastest
+    const int64_t per_sb = static_cast<int64_t>(FM_KT) * FM_IC;
+    const int64_t sb_per_row = (nkt + FM_KT - 1) / FM_KT;
+    const int64_t sb = blockIdx.x / per_sb, w = blockIdx.x - sb * per_sb;
+    const int64_t kt = (sb % sb_per_row) * FM_KT + (w % FM_KT);
+    const int64_t ic = (sb / sb_per_row) * FM_IC + (w / FM_KT);
+    if (kt >= nkt || ic >= nic) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t k0 = kt * 16, i0 = ic * 256 + wave * 64;
+    if (i0 >= m) return;
+    // A operand: row = lane & 15 -> column k0 + l15 of Binv, k-index = 4 step + (lane >> 4)
+    const int64_t kA = (k0 + l15 < m) ? k0 + l15 : m - 1;
+    double ra[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) ra[st] = P.R[kA + static_cast<int64_t>(4 * st + l4) * m];
+    // Row tiles in PAIRS with interleaved rows: MFMA column c of tile u (u = 0, 1) stands for row ip + 2 c + u of
+    // Binv, so a lane's two accumulator entries for one column of Binv are neighbours in memory and every access
+    // of Binv and of E is a 16-byte one (32 consecutive rows = 256 bytes per group of 16 lanes).
+    const bool even = (m & 1) == 0; // 16-byte alignment of every column needs an even m
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int64_t ip = i0 + 32 * t;
+        if (ip >= m) break;
+        const int64_t r0 = ip + 2 * l15; // this lane's two rows: r0, r0 + 1
+        const bool in0 = r0 < m, in1 = r0 + 1 < m;
+        const bool fast = even && in1; // (an odd m breaks the 16-byte alignment of the columns; the last lane may hold one row)
+        spx_v2d eb[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const double *e = P.E + static_cast<int64_t>(4 * st + l4) * m;
+            if (fast) eb[st] = *reinterpret_cast<const spx_v2d *>(e + r0);
+            else eb[st] = spx_v2d{in0 ? e[r0] : 0.0, in1 ? e[r0 + 1] : 0.0};
         }
-        (void)rocblas_set_pointer_mode(handles[device], rocblas_pointer_mode_host);
+        spx_v4d acc0, acc1;
+        double *cp[4];
+        bool okc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t kk = k0 + l4 + 4 * q;
+            okc[q] = kk < m;
+            cp[q] = P.Binv + (okc[q] ? kk : 0) * m;
+            spx_v2d c2;
+            if (fast) c2 = *reinterpret_cast<const spx_v2d *>(cp[q] + r0);
+            else c2 = spx_v2d{in0 ? cp[q][r0] : 0.0, in1 ? cp[q][r0 + 1] : 0.0};
+            acc0[q] = -c2.x; // accumulate  -Binv + R E^T  and flip the sign at the store
+            acc1[q] = -c2.y;
+        }
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[st], eb[st].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[st], eb[st].y, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!okc[q]) continue;
+            if (fast) {
+                *reinterpret_cast<spx_v2d *>(cp[q] + r0) = spx_v2d{-acc0[q], -acc1[q]};
+            } else {
+                if (in0) cp[q][r0] = -acc0[q];
+                if (in1) cp[q][r0 + 1] = -acc1[q];
+            }
+        }
     }
-    if (rocblas_set_stream(handles[device], s) != rocblas_status_success) return nullptr;
-    return handles[device];
 }
 
 // Binv -= dhat * rho^T with dhat_i = d_i/alpha (i != r), dhat_r = (alpha - 1)/alpha
@@ -1401,18 +1468,21 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
     };
     const int fold_col_tiles = static_cast<int>((m + FOLD_COLS - 1) / FOLD_COLS);
     const unsigned fold_grid = static_cast<unsigned>(((m + SX_WG - 1) / SX_WG) * fold_col_tiles);
-    // large inverses fold through the library DGEMM (never inside a stream capture: see enqueue_batch)
-    static const char *blas_env = getenv("SX_SPX_BLAS"); // "0": the library's own fold kernel at every size (A/B runs)
-    rocblas_handle blas = (defer && m >= SPX_BLAS_MIN_M && !(blas_env && blas_env[0] == '0')) ? spx_blas(ctx->device, s) : nullptr;
+    // large inverses fold on the matrix cores (k_spx_fold_mfma), small ones by the scalar kernel in pivot order
+    static const char *blas_env = getenv("SX_SPX_BLAS"); // "0": the scalar fold kernel at every size (A/B runs)
+    // measured at m = 2e4 (tools/fold_bench.py, profiles/r03/spx_fold.md): scalar kernel 1.76 ms per fold, this
+    // matrix-core kernel 2.2 ms, the vendor DGEMM it replaced 1.46 ms -- so the scalar kernel is the default and the
+    // matrix-core one is kept for the record (and its tests) behind SX_SPX_FOLD_MFMA_MIN = rows from which it runs
+    const char *fm_env = getenv("SX_SPX_FOLD_MFMA_MIN");
+    const int64_t fm_min = fm_env ? atoll(fm_env) : INT64_MAX;
+    const bool fold_mfma = defer && m >= fm_min && !(blas_env && blas_env[0] == '0');
+    const int64_t fm_nkt = (m + 15) / 16, fm_nic = (m + 255) / 256;
+    const unsigned fm_grid = static_cast<unsigned>(((fm_nkt + FM_KT - 1) / FM_KT) * ((fm_nic + FM_IC - 1) / FM_IC) * FM_KT * FM_IC);
     auto fold = [&](int cnt) {
-        if (blas) {
-            hipLaunchKernelGGL(k_spx_fold_mask, dim3(gM, SPX_DEFER), dim3(SX_WG), 0, s, P, cnt);
-            const double alpha = -1.0, beta = 1.0;
-            if (rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, static_cast<rocblas_int>(m),
-                              static_cast<rocblas_int>(m), SPX_DEFER, &alpha, P.E, static_cast<rocblas_int>(m), P.R,
-                              static_cast<rocblas_int>(m), &beta, P.Binv, static_cast<rocblas_int>(m)) == rocblas_status_success)
-                return;
-            blas = nullptr; // (the columns are masked: the kernel below does the same update)
+        if (fold_mfma) {
+            hipLaunchKernelGGL(k_spx_fold_mask, dim3(gM, SPX_DEFER), dim3(SX_WG), 0, s, P, cnt); // empty slots: zero columns
+            hipLaunchKernelGGL(k_spx_fold_mfma, dim3(fm_grid), dim3(SX_WG), 0, s, P, fm_nkt, fm_nic);
+            return;
         }
         hipLaunchKernelGGL(k_spx_fold, dim3(fold_grid), dim3(SX_WG), 0, s, P, cnt, fold_col_tiles);
     };
@@ -1617,8 +1687,8 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
         // (profiles/r01/spx_bench.txt), so a profiled run simply does not replay
         if (getenv("ROCP_TOOL_LIBRARIES") != nullptr) return;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            graph_has_fold = blas == nullptr;
-            enqueue_batch(graph_has_fold); // a library call stays out of the capture: it follows the replay
+            graph_has_fold = true;
+            enqueue_batch(graph_has_fold);
             if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
                 hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 exec = nullptr;

@@ -355,3 +355,24 @@ def test_perturbation_crossover_re_solves_on_the_device():
     assert "Getting and solving a perturb subproblem" in text
     if "A primal optimal BFS is found" not in text:
         check_vertex(lp, out, ref.obj_val)
+
+
+@pytest.mark.parametrize("m,n,k,seed", [(37, 90, 3, 1), (300, 900, 4, 2), (1000, 2500, 5, 3)])
+def test_matrix_core_fold_agrees_with_the_scalar_fold(monkeypatch, m, n, k, seed):
+    """The rank-64 update of the dense inverse on the fp64 matrix cores (k_spx_fold_mfma; by default from 8192 rows
+    on) forced on at small sizes whose row counts are no multiples of its 16 / 64 / 256 tiles: same optimum as HiGHS
+    and as the scalar fold, the final basis a fixed point."""
+    from smart_crossover.solver_caller.solving import solve_lp
+    inst = workloads.sparse_lp(m, n, k, seed=seed, stratified=False, frac_upper=0.4)
+    lp = general_lp(inst)
+    ref = solve_lp(lp, "HGS", "default", settings())
+    assert ref.status == "OPTIMAL"
+    outs = {}
+    for mode in ("1", "1000000"):
+        monkeypatch.setenv("SX_SPX_FOLD_MFMA_MIN", mode)
+        out = solve_lp(lp, "HIP", "primal_simplex", settings())
+        check_vertex(lp, out, ref.obj_val)
+        again = solve_lp(lp, "HIP", "default", settings(), warm_start_basis=out.basis)
+        assert again.iter_count == 0
+        outs[mode] = out
+    assert outs["1"].obj_val == pytest.approx(outs["1000000"].obj_val, rel=1e-10)
