@@ -395,6 +395,9 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=0,
                     help="also time this many iterations of the column-sharded projector CG (one m-vector all-reduce per "
                          "iteration over RCCL at N > 1): reported under 'sharded_cg', not part of the step")
+    ap.add_argument("--pricing-rounds", type=int, default=50,
+                    help="also time this many pricing rounds of a column-sharded simplex pivot (K10 on the rank's block + "
+                         "the all-gather of the 24-byte records at N > 1): reported under 'sharded_pricing' (0: skip)")
     ap.add_argument("--c4-highs", action="store_true",
                     help="time config 4's network crossover with the re-solves in HiGHS too (94 s on the box's host cores; "
                          "without it the line quotes profiles/r02/netdual_c4_highs.jsonl)")
@@ -550,6 +553,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- pricing rounds of a column-sharded simplex pivot (ShardedLP.simplex_price): K10 over the rank's column block
+    # + ONE all-gather of the 24-byte records; the rest of a pivot (FTRAN, ratio test, update) is replicated
+    sharded_pricing = None
+    if args.pricing_rounds > 0:
+        try:
+            def pricing_round():
+                ctx.price(dC, d_y, d_c, vb, 1e-6, None, price)
+                if use_dist and not rehearse:
+                    dist.all_gather_into_tensor(t_gather, t_rec)
+                elif rehearse:
+                    cpu_gather = torch.empty(48 * world, dtype=torch.uint8)
+                    dist.all_gather_into_tensor(cpu_gather, t_rec.cpu())
+                    t_gather.copy_(cpu_gather)
+            for _ in range(3):
+                pricing_round()
+            fence()
+            t_pr = time.perf_counter()
+            for _ in range(args.pricing_rounds):
+                pricing_round()
+            fence()
+            pr_elapsed = time.perf_counter() - t_pr
+            if use_dist:
+                tt = torch.tensor([pr_elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                pr_elapsed = float(tt.item())
+            sharded_pricing = {"rounds": args.pricing_rounds, "us_per_round": pr_elapsed / args.pricing_rounds * 1e6,
+                               "pivots_per_s_bound": args.pricing_rounds / pr_elapsed,
+                               "columns_priced_per_round": int(world * n_loc),
+                               "exchange": f"all_gather of {world} x 24-byte pricing records" if world > 1 else "none (one rank)",
+                               "note": "the sharded part of a pivot (smart_crossover.distributed.ShardedLP.simplex_price); FTRAN, "
+                                       "ratio test and basis update are replicated"}
+        except Exception as exc:          # (the matrices were freed for the no-locality record: skip)
+            sharded_pricing = {"skipped": type(exc).__name__}
 
     k1_list = [ctx.marker_elapsed(5 * i, 5 * i + 1) for i in range(n_marked)]
     k2_list = [ctx.marker_elapsed(5 * i + 1, 5 * i + 2) for i in range(n_marked)]
@@ -751,6 +788,7 @@ def main():
             "roofline_uniform": uniform,
             "cpu_baseline": cpu,
             "sharded_cg": sharded_cg,
+            "sharded_pricing": sharded_pricing,
             "crossover": crossover,
             "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),
                        "min_rc": mn, "argmin": am, "n_violating": bad},

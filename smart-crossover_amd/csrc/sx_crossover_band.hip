@@ -38,6 +38,7 @@ struct TbState {
     int r;       // leaving position (-1: bound flip of the entering column)
     int hit;     // bound the leaving variable stops at: 1 lower, 2 upper
     int n_inf;
+    int b_lo, b_hi; // first / last block of 256 positions in which the entering column has an entry
     int pad;
     double theta, alpha_r, dq, sum_inf, feas_tol, opt_tol, tmax;
 };
@@ -84,6 +85,12 @@ __device__ __forceinline__ double tb_block_sum(double v, double *sm) {
     double r = ((sm[0] + sm[1]) + sm[2]) + sm[3];
     __syncthreads();
     return r;
+}
+
+// entries below the drop tolerance -> exact zeros (what the pivots skip)
+__global__ __launch_bounds__(TB_WG) void k_tb_drop(int64_t total, double *__restrict__ W, double tol) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
+    if (t < total && fabs(W[t]) < tol) W[t] = 0.0;
 }
 
 // out[s] = base[s] - sum_p w[p] T[p, s]        (one workgroup per tracked column)
@@ -270,13 +277,17 @@ __global__ __launch_bounds__(TB_WG) void k_tb_ratio1(int64_t m, const double *__
                                                      const TbState *__restrict__ st, double *__restrict__ eta,
                                                      double *__restrict__ part) {
     __shared__ double sm[TB_WG];
+    __shared__ int any_nz;
     if (st->status != 0) return;
+    if (threadIdx.x == 0) any_nz = 0;
+    __syncthreads();
     const int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
     const double dir = static_cast<double>(st->dir), tol = st->feas_tol;
     double t = INFINITY;
     if (p < m) {
         const double a = T[static_cast<size_t>(st->q) * m + p];
         eta[static_cast<size_t>(st->n_eta) * m + p] = a;
+        if (a != 0.0) any_nz = 1; // (benign race: every writer stores 1)
         if (fabs(a) > TB_PIV) {
             double dist, rate;
             int hit;
@@ -290,14 +301,42 @@ __global__ __launch_bounds__(TB_WG) void k_tb_ratio1(int64_t m, const double *__
         if (threadIdx.x < o) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = sm[0];
+        part[gridDim.x + blockIdx.x] = any_nz ? 1.0 : 0.0;
+    }
 }
 
-__global__ void k_tb_tmax(int nblk, const double *__restrict__ part, TbState *st) {
+__global__ __launch_bounds__(TB_WG) void k_tb_tmax(int nblk, const double *__restrict__ part, TbState *st) {
+    __shared__ double sm[TB_WG];
+    __shared__ int slo[TB_WG], shi[TB_WG];
     if (st->status != 0) return;
     double t = INFINITY;
-    for (int k = 0; k < nblk; ++k) t = fmin(t, part[k]);
-    st->tmax = t;
+    int lo = nblk, hi = -1;
+    for (int k = threadIdx.x; k < nblk; k += TB_WG) {
+        t = fmin(t, part[k]);
+        if (part[nblk + k] != 0.0) {
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+        }
+    }
+    sm[threadIdx.x] = t;
+    slo[threadIdx.x] = lo;
+    shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = TB_WG / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + o]);
+            slo[threadIdx.x] = min(slo[threadIdx.x], slo[threadIdx.x + o]);
+            shi[threadIdx.x] = max(shi[threadIdx.x], shi[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->tmax = sm[0];
+        st->b_lo = slo[0];
+        st->b_hi = shi[0];
+    }
 }
 
 __global__ __launch_bounds__(TB_WG) void k_tb_ratio(int64_t m, const double *__restrict__ xB, const double *__restrict__ lB,
@@ -389,35 +428,37 @@ __global__ __launch_bounds__(TB_WG) void k_tb_rowcopy(int64_t m, int64_t nJ, con
     if (s == st->q) st->alpha_r = v;
 }
 
-// x_B, and on a basis change the rank-one update of the tableau.  grid: (positions / 256, slot blocks of 32)
+// x_B, and on a basis change the rank-one update of the tableau.  grid: (row workgroups, slot blocks of 32); the
+// row workgroups stride over the blocks of 256 positions [b_lo, b_hi] in which the entering column has an entry at
+// all -- B^-1 a_q of a band basis is local, so at 1e6 rows a pivot touches a few thousand of them.
 __global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, int64_t nJ, double *__restrict__ T, double *__restrict__ xB,
                                                      const double *__restrict__ eta, const double *__restrict__ rowbuf,
                                                      const TbState *__restrict__ st) {
     if (st->status != 0) return;
-    const int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
-    if (p >= m) return;
-    const double a = eta[static_cast<size_t>(st->n_eta) * m + p];
     const int r = st->r, q = st->q;
-    if (blockIdx.y == 0) {
-        if (p != r) xB[p] = xB[p] - static_cast<double>(st->dir) * st->theta * a;
-    }
-    if (r < 0) return;
     const double ar = st->alpha_r;
     const int64_t s0 = static_cast<int64_t>(blockIdx.y) * 32, s1 = (s0 + 32 < nJ) ? s0 + 32 : nJ;
-    if (p == r) {
-        for (int64_t s = s0; s < s1; ++s) T[static_cast<size_t>(s) * m + p] = (s == q) ? 1.0 / ar : rowbuf[s] / ar;
-        return;
-    }
-    if (a == 0.0) return; // the row does not see this pivot
-    const double f = a / ar;
-    for (int64_t s = s0; s < s1; ++s) {
-        if (s == q) {
-            T[static_cast<size_t>(s) * m + p] = -f;
-        } else {
-            const double rb = rowbuf[s];
-            if (rb != 0.0) {
-                double *t = T + static_cast<size_t>(s) * m + p;
-                *t = *t - f * rb;
+    for (int64_t rb = st->b_lo + blockIdx.x; rb <= st->b_hi; rb += gridDim.x) {
+        const int64_t p = rb * TB_WG + threadIdx.x;
+        if (p >= m) continue;
+        const double a = eta[static_cast<size_t>(st->n_eta) * m + p];
+        if (blockIdx.y == 0 && p != r) xB[p] = xB[p] - static_cast<double>(st->dir) * st->theta * a;
+        if (r < 0) continue;
+        if (p == r) {
+            for (int64_t s = s0; s < s1; ++s) T[static_cast<size_t>(s) * m + p] = (s == q) ? 1.0 / ar : rowbuf[s] / ar;
+            continue;
+        }
+        if (a == 0.0) continue; // the row does not see this pivot
+        const double f = a / ar;
+        for (int64_t s = s0; s < s1; ++s) {
+            if (s == q) {
+                T[static_cast<size_t>(s) * m + p] = -f;
+            } else {
+                const double rb_ = rowbuf[s];
+                if (rb_ != 0.0) {
+                    double *t = T + static_cast<size_t>(s) * m + p;
+                    *t = *t - f * rb_;
+                }
             }
         }
     }
@@ -656,16 +697,12 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     // basis changes before the basis is factored afresh (bounds the eta file and the drift of the tableau).  A fresh
     // start covers the dense rows by their logicals again, so it is not free: as many as a quarter of the memory holds
     int64_t EPOCH = 4096;
-    int64_t capJ = static_cast<int64_t>(tracked.size()) + std::max<int64_t>(4096, static_cast<int64_t>(tracked.size()) / 2);
+    int64_t capJ = 0; // fixed once the first matching has told how many columns start outside the basis
     {
         size_t free_b = 0, total_b = 0;
         SX_HIP(hipMemGetInfo(&free_b, &total_b));
         EPOCH = std::min<int64_t>(20000, std::max<int64_t>(1024, static_cast<int64_t>(0.25 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m)))));
         if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
-        if ((static_cast<double>(capJ) + static_cast<double>(EPOCH) + 1.0) * m * 8.0 > 0.85 * static_cast<double>(free_b)) {
-            sx_set_error("the tableau of %lld tracked columns over %lld rows does not fit the free device memory", (long long)capJ, (long long)m);
-            return SX_ERR_NOMEM;
-        }
     }
     double *d_T = nullptr, *d_eta = nullptr, *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr;
     double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
@@ -674,8 +711,6 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     TbPart *d_rpart = nullptr;
     TbState *d_st = nullptr;
     const int nblk = static_cast<int>(gridof(m));
-    SX_TRY(dev.get(static_cast<size_t>(m) * capJ, &d_T));
-    SX_TRY(dev.get(static_cast<size_t>(m) * (EPOCH + 1), &d_eta));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_xB));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_lB));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_uB));
@@ -683,16 +718,6 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     SX_TRY(dev.get(static_cast<size_t>(m), &d_g));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_vec));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_head));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_xJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_lJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_uJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_cJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_dJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_d1));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_rowbuf));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_varJ));
-    SX_TRY(dev.get(static_cast<size_t>(capJ), &d_statJ));
-    SX_TRY(dev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
     SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_part));
     SX_TRY(dev.get(static_cast<size_t>(nblk), &d_rpart));
     SX_TRY(dev.get(1, &d_st));
@@ -833,6 +858,32 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 varJ.push_back(v);
             }
         int64_t nJ = static_cast<int64_t>(varJ.size());
+        if (capJ == 0) {
+            capJ = nJ + std::max<int64_t>(4096, nJ / 2);
+            size_t free_b = 0, total_b = 0;
+            SX_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (static_cast<double>(capJ) * m * 8.0 > 0.9 * static_cast<double>(free_b)) capJ = nJ + 1024;
+            if (static_cast<double>(capJ) * m * 8.0 > 0.95 * static_cast<double>(free_b)) {
+                sx_set_error("the tableau of %lld tracked columns over %lld rows does not fit the free device memory", (long long)capJ, (long long)m);
+                return SX_ERR_NOMEM;
+            }
+            SX_TRY(dev.get(static_cast<size_t>(m) * capJ, &d_T));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_xJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_lJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_uJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_cJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_dJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_d1));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_rowbuf));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_varJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_statJ));
+            // the eta file takes what is left (up to 20,000 basis changes)
+            SX_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (!getenv("SX_BAND_EPOCH"))
+                EPOCH = std::min<int64_t>(20000, std::max<int64_t>(256, static_cast<int64_t>(0.8 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m))) - 1));
+            SX_TRY(dev.get(static_cast<size_t>(m) * (EPOCH + 1), &d_eta));
+            SX_TRY(dev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
+        }
         if (nJ > capJ) {
             sx_set_error("the tracked columns (%lld) outgrew the tableau (%lld)", (long long)nJ, (long long)capJ);
             return SX_ERR_NOMEM;
@@ -973,6 +1024,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_HIP(hipMemsetAsync(W, 0, sizeof(double) * static_cast<size_t>(m) * k, s));
             hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(k)), dim3(TB_WG), 0, s, k, d_varJ + s0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, W, m);
             SX_TRY(ftran_cols(W, k, n_eta_now));
+            hipLaunchKernelGGL(k_tb_drop, dim3(gridof(m * k)), dim3(TB_WG), 0, s, m * k, W, 1e-13);
             // reduced costs of the new columns under the current basis: d = c_J - c_B^T T
             hipLaunchKernelGGL(k_tb_coldot, dim3(static_cast<unsigned>(k)), dim3(TB_WG), 0, s, m, W, d_cB, d_cJ + s0, d_dJ + s0);
             SX_HIP(hipGetLastError());
@@ -998,11 +1050,11 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, d_T, d_g, d_st, d_d1);
             hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
             hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part);
-            hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(1), 0, s, nblk, d_part, d_st);
+            hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st);
             hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
             hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(1), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
             hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_st, d_rowbuf);
-            hipLaunchKernelGGL(k_tb_update, dim3(nblk, static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st);
+            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st);
             hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, d_varJ, d_xJ, d_lJ, d_uJ,
                                d_cJ, d_statJ, d_eta_r, d_st);
         };

@@ -318,6 +318,10 @@ class ShardedLP:
         self.l_all, self.u_all = v(lp.l), v(lp.u)
         self.lt = np.asarray(lp.sense) == "<"
         self.n_lt = int(np.count_nonzero(self.lt))
+        # host copies the sharded simplex driver needs (entering-column fetch, replicated right-hand side and costs)
+        self._A_cols_host = A[:, cs:ce].tocsc()
+        self._b_host = np.asarray(lp.b, dtype=np.float64).copy()
+        self._c_host = np.asarray(lp.c, dtype=np.float64).copy()
 
     # ---- K1 + K2 + set sizes + K10 ------------------------------------------------------------------
     def scoring_pass(self, x: np.ndarray, y: np.ndarray, gamma: float, gamma_dual: float):
@@ -401,6 +405,150 @@ class ShardedLP:
         return torch.cat([out[r * longest:r * longest + int(k)] for r, k in enumerate(sizes)])
 
     # ---- K6: right-hand side of the sub-problem, exact --------------------------------------------------
+    # ---- K16 over column shards: the pricing minimum is global, everything else replicated ------------------
+    def simplex_price(self, y: np.ndarray, vbasis_loc: np.ndarray, tol: float = 1e-6):
+        """One pricing round of a column-sharded simplex pivot (reference: the pricing the re-solves hide inside the
+        solver, globalised as net_manager.py:293-319 globalises its optimality test): the rank-local K10 walk over the
+        own column block -- reduced cost c_j - a_j^T y, sign flipped at an upper bound, basic columns price at 0 --
+        leaves one 24-byte record (value, column, violations); ONE all-gather later every rank holds the same global
+        entering column (most negative value, ties to the smallest global column)."""
+        return self.price(y, vbasis_loc, tol)
+
+    def primal_simplex(self, max_iter: int = 100000, opt_tol: float = 1e-9, trace: Optional[list] = None):
+        """Bounded primal simplex (Dantzig pricing, textbook ratio test, ties to the smallest index) on
+        ``min c^T x, A x <= b, l <= x <= u`` from the slack basis, which must be feasible (b - A l >= 0, every row
+        '<', l finite).  What is SHARDED is what scales with the columns: pricing (``simplex_price``: K10 on the
+        rank's block + the 24-byte all-gather) and the fetch of the entering column (its owner broadcasts it: 8 m
+        bytes); FTRAN, ratio test and the basis inverse (dense, on the host: this driver is for sub-problems of a
+        few thousand rows) are replicated and run identically on every rank, so every rank makes the same pivots.
+        The single-GPU solver with the basis on the device is sx_simplex_solve_dev.  Returns x (this rank's block),
+        y, the global pivot sequence [(entering variable, leaving position)] and the status."""
+        import torch
+        o = self.ops
+        m, cs, ce = self.m, self.cols.start, self.cols.stop
+        n_loc = ce - cs
+        if not bool(np.all(self.lt)):
+            raise ValueError("primal_simplex starts from the slack basis: every row must be '<'")
+        l_loc, u_loc, c_loc = (np.asarray(o.host(t), dtype=np.float64) for t in (self.l_loc, self.u_loc, self.c_loc))
+        l_all, u_all = np.asarray(o.host(self.l_all)), np.asarray(o.host(self.u_all))
+        if not np.all(np.isfinite(l_all)):
+            raise ValueError("primal_simplex needs finite lower bounds")
+        A_loc = self._host_cols()                              # this rank's columns on the host (entering-column fetch)
+        # b - A l: every rank's share of A l summed over the ranks (one m-vector all-reduce, once)
+        t = torch.from_numpy(np.ascontiguousarray(A_loc @ l_loc))
+        t = t.to(getattr(o, "device", "cpu"))
+        self._allreduce(t)
+        b_all = self._b_all()
+        xB = b_all - t.cpu().numpy()                           # slacks basic
+        if xB.min() < -1e-12:
+            raise ValueError("the slack basis is not feasible")
+        n = self.n
+        head = np.arange(n, n + m)                             # variable at every basis position (logical of row i: n + i)
+        Binv = np.eye(m)
+        vb_loc = np.full(n_loc, -1, dtype=np.int8)             # -1 at lower, -2 at upper, 0 basic
+        x_loc = l_loc.copy()
+        cB = np.zeros(m)
+        lB, uB = np.zeros(m), np.full(m, np.inf)
+        logical_nb = np.zeros(m, dtype=bool)                   # logicals that left the basis (non-basic at 0)
+        pivots, status = [], "ITERATION_LIMIT"
+        owners = [b.start for b in self.col_blocks]
+        for it in range(int(max_iter)):
+            y = Binv.T @ cB
+            rc_min, gcol, _ = self.simplex_price(y, vb_loc, opt_tol)          # <- the exchange of this pivot
+            # non-basic logicals (replicated): reduced cost -y_i at 0
+            li = -1
+            if logical_nb.any():
+                d = np.where(logical_nb, -y, np.inf)
+                li = int(np.argmin(d))
+                if not (d[li] < -opt_tol):
+                    li = -1
+            take_logical = li >= 0 and (gcol < 0 or not (rc_min < -opt_tol) or -y[li] < rc_min)
+            if not take_logical and (gcol < 0 or not (rc_min < -opt_tol)):
+                status = "OPTIMAL"
+                break
+            if take_logical:
+                q, a_q, direction, own_range = n + li, np.zeros(m), 1.0, np.inf
+                a_q[li] = 1.0
+            else:
+                q = int(gcol)
+                owner = int(np.searchsorted(owners, q, side="right") - 1)
+                col = torch.zeros(m + 2, dtype=torch.float64)
+                if owner == self.ex.rank:
+                    j = q - cs
+                    col[:m] = torch.from_numpy(np.asarray(A_loc[:, j].todense()).ravel())
+                    col[m] = -1.0 if vb_loc[j] == -2 else 1.0
+                    col[m + 1] = u_loc[j] - l_loc[j]
+                col = col.to(getattr(o, "device", "cpu"))
+                if self.dist is not None:
+                    self.dist.broadcast(col, src=owner)
+                colh = col.cpu().numpy()
+                a_q, direction, own_range = colh[:m], float(colh[m]), float(colh[m + 1])
+            alpha = Binv @ a_q
+            rate = -direction * alpha                           # change of x_B per unit step
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t_lo = np.where(rate < -1e-11, (xB - lB) / -rate, np.inf)
+                t_up = np.where((rate > 1e-11) & np.isfinite(uB), (uB - xB) / rate, np.inf)
+            tt = np.minimum(t_lo, t_up)
+            r = int(np.argmin(tt))
+            theta = max(float(tt[r]), 0.0)
+            if own_range <= theta:                              # the entering column reaches its other bound first
+                if not np.isfinite(own_range):
+                    status = "UNBOUNDED"
+                    break
+                xB = xB + rate * own_range
+                if not take_logical and owner == self.ex.rank:
+                    j = q - cs
+                    vb_loc[j] = -1 if vb_loc[j] == -2 else -2
+                    x_loc[j] = u_loc[j] if vb_loc[j] == -2 else l_loc[j]
+                pivots.append((q, -1))
+                continue
+            if not np.isfinite(theta):
+                status = "UNBOUNDED"
+                break
+            hit_upper = t_up[r] <= t_lo[r]
+            xB = xB + rate * theta
+            vout = int(head[r])
+            # leaving variable -> non-basic at the bound it hit
+            if vout >= n:
+                logical_nb[vout - n] = True
+            elif cs <= vout < ce:
+                vb_loc[vout - cs] = -2 if hit_upper else -1
+                x_loc[vout - cs] = u_loc[vout - cs] if hit_upper else l_loc[vout - cs]
+            # entering variable -> position r
+            if take_logical:
+                logical_nb[li] = False
+                x_new, lo_q, up_q, c_q = theta, 0.0, np.inf, 0.0
+            else:
+                lo_q, up_q = float(l_all[q]), float(u_all[q])
+                x_new = (up_q - theta) if direction < 0 else (lo_q + theta)
+                c_q = self._cost_of(q)
+                if owner == self.ex.rank:
+                    vb_loc[q - cs] = 0
+            head[r], xB[r], lB[r], uB[r], cB[r] = q, x_new, lo_q, up_q, c_q
+            piv = alpha[r]
+            row = Binv[r] / piv
+            Binv = Binv - np.outer(alpha, row)
+            Binv[r] = row
+            pivots.append((q, r))
+        if trace is not None:
+            trace.extend(pivots)
+        for p in range(m):                                      # basic structurals of this block: their values
+            if head[p] < n and cs <= head[p] < ce:
+                x_loc[head[p] - cs] = xB[p]
+        return x_loc, Binv.T @ cB, pivots, status
+
+    def _host_cols(self):
+        import scipy.sparse as sp
+        if getattr(self, "_A_cols_host", None) is None:
+            raise ValueError("ShardedLP was built without keep_host=True")
+        return sp.csc_matrix(self._A_cols_host)
+
+    def _b_all(self) -> np.ndarray:
+        return self._b_host
+
+    def _cost_of(self, q: int) -> float:
+        return float(self._c_host[q])
+
     def sub_problem_rhs(self):
         """b - A[:, fix_up] u - A[:, fix_low] l for the own rows after ``scoring_pass`` -- every row is summed by
         the rank that owns it, over all columns, so the result equals the single-GPU one bit for bit; the codes

@@ -97,3 +97,25 @@ def test_sharded_path_with_three_ranks(tmp_path):
     res = run_workers("_dist_worker2.py", tmp_path / "res.json", 3)
     assert res["world"] == 3
     check_sharded_results(res)
+
+
+def test_column_sharded_simplex_makes_the_single_process_pivots(tmp_path):
+    """ShardedLP.primal_simplex: one pricing all-gather (24 bytes per rank) and one broadcast of the entering column
+    per pivot, everything else replicated.  Two and three gloo ranks make exactly the pivots of the single process
+    (>= 100 of them) and reach HiGHS' optimum."""
+    import importlib.util
+    import numpy as np
+    from scipy.optimize import linprog
+    single = run_workers("_dist_worker3.py", tmp_path / "w1.json", 1)
+    assert single["status"] == "OPTIMAL" and len(single["pivots"]) >= 100
+    spec = importlib.util.spec_from_file_location("w3", os.path.join(HERE, "_dist_worker3.py"))
+    w3 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w3)
+    lp = w3.problem()
+    ref = linprog(lp.c, A_ub=lp.A, b_ub=lp.b, bounds=np.c_[lp.l, lp.u], method="highs")
+    assert ref.status == 0 and single["obj"] == pytest.approx(ref.fun, rel=1e-9)
+    for world in (2, 3):
+        res = run_workers("_dist_worker3.py", tmp_path / f"w{world}.json", world)
+        assert res["world"] == world and res["status"] == "OPTIMAL"
+        assert res["pivots"] == single["pivots"]
+        assert res["obj"] == pytest.approx(single["obj"], rel=1e-12)
