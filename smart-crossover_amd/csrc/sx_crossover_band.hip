@@ -38,7 +38,8 @@ struct TbState {
     int r;       // leaving position (-1: bound flip of the entering column)
     int hit;     // bound the leaving variable stops at: 1 lower, 2 upper
     int n_inf;
-    int b_lo, b_hi; // first / last block of 256 positions in which the entering column has an entry
+    int n_bl;       // blocks of 256 positions in which the entering column has an entry (their list: blist)
+    int b_pad;
     int pad;
     double theta, alpha_r, dq, sum_inf, feas_tol, opt_tol, tmax;
 };
@@ -148,17 +149,31 @@ __global__ void k_tb_phase(int nblk, const double *__restrict__ part, TbState *s
     st->phase = cnt > 0.0 ? 1 : 2;
 }
 
-// phase 1 only: d1[s] = - sum_p g[p] T[p, s]
-__global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, const double *__restrict__ T, const double *__restrict__ g,
-                                                     const TbState *__restrict__ st, double *__restrict__ d1) {
+// phase 1 only: d1[s] = - sum_p g[p] T[p, s].  Few basic variables are infeasible behind a first-order point, so
+// a workgroup (one per tracked column) visits only the blocks of 256 positions that hold one (counts from
+// k_tb_infeas), a lane per block; with many of them it reads the column whole, coalesced.
+__global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const double *__restrict__ T, const double *__restrict__ g,
+                                                     const double *__restrict__ part, const TbState *__restrict__ st,
+                                                     double *__restrict__ d1) {
     __shared__ double sm[4];
     if (st->status != 0 || st->phase != 1) return;
     const int64_t s = blockIdx.x;
     const double *col = T + static_cast<size_t>(s) * m;
     double acc = 0.0;
-    for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
-        const double gp = g[p];
-        if (gp != 0.0) acc += gp * col[p];
+    if (st->n_inf <= 4096) {
+        for (int k = threadIdx.x; k < nblk; k += TB_WG)
+            if (part[2 * k] > 0.0) {
+                const int64_t p0 = static_cast<int64_t>(k) * TB_WG, p1 = (p0 + TB_WG < m) ? p0 + TB_WG : m;
+                for (int64_t p = p0; p < p1; ++p) {
+                    const double gp = g[p];
+                    if (gp != 0.0) acc += gp * col[p];
+                }
+            }
+    } else {
+        for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
+            const double gp = g[p];
+            if (gp != 0.0) acc += gp * col[p];
+        }
     }
     const double tot = tb_block_sum(acc, sm);
     if (threadIdx.x == 0) d1[s] = -tot;
@@ -307,36 +322,38 @@ __global__ __launch_bounds__(TB_WG) void k_tb_ratio1(int64_t m, const double *__
     }
 }
 
-__global__ __launch_bounds__(TB_WG) void k_tb_tmax(int nblk, const double *__restrict__ part, TbState *st) {
+__global__ __launch_bounds__(TB_WG) void k_tb_tmax(int nblk, const double *__restrict__ part, TbState *st, int32_t *__restrict__ blist) {
     __shared__ double sm[TB_WG];
-    __shared__ int slo[TB_WG], shi[TB_WG];
+    __shared__ int cnt[TB_WG];
     if (st->status != 0) return;
+    // every lane a contiguous run of blocks: the list comes out in ascending order whatever the run lengths
+    const int per = (nblk + TB_WG - 1) / TB_WG;
+    const int k0 = threadIdx.x * per, k1 = (k0 + per < nblk) ? k0 + per : nblk;
     double t = INFINITY;
-    int lo = nblk, hi = -1;
-    for (int k = threadIdx.x; k < nblk; k += TB_WG) {
+    int mine = 0;
+    for (int k = k0; k < k1; ++k) {
         t = fmin(t, part[k]);
-        if (part[nblk + k] != 0.0) {
-            lo = k < lo ? k : lo;
-            hi = k > hi ? k : hi;
-        }
+        if (part[nblk + k] != 0.0) ++mine;
     }
     sm[threadIdx.x] = t;
-    slo[threadIdx.x] = lo;
-    shi[threadIdx.x] = hi;
+    cnt[threadIdx.x] = mine;
     __syncthreads();
-    for (int o = TB_WG / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + o]);
-            slo[threadIdx.x] = min(slo[threadIdx.x], slo[threadIdx.x + o]);
-            shi[threadIdx.x] = max(shi[threadIdx.x], shi[threadIdx.x + o]);
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        st->tmax = sm[0];
-        st->b_lo = slo[0];
-        st->b_hi = shi[0];
+        double tm = INFINITY;
+        int run = 0;
+        for (int w = 0; w < TB_WG; ++w) {
+            tm = fmin(tm, sm[w]);
+            const int c = cnt[w];
+            cnt[w] = run;
+            run += c;
+        }
+        st->tmax = tm;
+        st->n_bl = run;
     }
+    __syncthreads();
+    int o = cnt[threadIdx.x];
+    for (int k = k0; k < k1; ++k)
+        if (part[nblk + k] != 0.0) blist[o++] = k;
 }
 
 __global__ __launch_bounds__(TB_WG) void k_tb_ratio(int64_t m, const double *__restrict__ xB, const double *__restrict__ lB,
@@ -429,17 +446,17 @@ __global__ __launch_bounds__(TB_WG) void k_tb_rowcopy(int64_t m, int64_t nJ, con
 }
 
 // x_B, and on a basis change the rank-one update of the tableau.  grid: (row workgroups, slot blocks of 32); the
-// row workgroups stride over the blocks of 256 positions [b_lo, b_hi] in which the entering column has an entry at
-// all -- B^-1 a_q of a band basis is local, so at 1e6 rows a pivot touches a few thousand of them.
+// row workgroups stride over the LIST of blocks of 256 positions in which the entering column has an entry at all --
+// B^-1 a_q of a band basis is local (plus the dense rows at the end), so at 1e6 rows a pivot touches a few thousand.
 __global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, int64_t nJ, double *__restrict__ T, double *__restrict__ xB,
                                                      const double *__restrict__ eta, const double *__restrict__ rowbuf,
-                                                     const TbState *__restrict__ st) {
+                                                     const TbState *__restrict__ st, const int32_t *__restrict__ blist) {
     if (st->status != 0) return;
     const int r = st->r, q = st->q;
     const double ar = st->alpha_r;
     const int64_t s0 = static_cast<int64_t>(blockIdx.y) * 32, s1 = (s0 + 32 < nJ) ? s0 + 32 : nJ;
-    for (int64_t rb = st->b_lo + blockIdx.x; rb <= st->b_hi; rb += gridDim.x) {
-        const int64_t p = rb * TB_WG + threadIdx.x;
+    for (int e = blockIdx.x; e < st->n_bl; e += gridDim.x) {
+        const int64_t p = static_cast<int64_t>(blist[e]) * TB_WG + threadIdx.x;
         if (p >= m) continue;
         const double a = eta[static_cast<size_t>(st->n_eta) * m + p];
         if (blockIdx.y == 0 && p != r) xB[p] = xB[p] - static_cast<double>(st->dir) * st->theta * a;
@@ -706,8 +723,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     }
     double *d_T = nullptr, *d_eta = nullptr, *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr;
     double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
-           *d_part = nullptr, *d_vec = nullptr;
-    int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr;
+           *d_part = nullptr, *d_infpart = nullptr, *d_vec = nullptr;
+    int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr, *d_blist = nullptr;
     TbPart *d_rpart = nullptr;
     TbState *d_st = nullptr;
     const int nblk = static_cast<int>(gridof(m));
@@ -719,6 +736,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     SX_TRY(dev.get(static_cast<size_t>(m), &d_vec));
     SX_TRY(dev.get(static_cast<size_t>(m), &d_head));
     SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_part));
+    SX_TRY(dev.get(static_cast<size_t>(nblk), &d_blist));
+    SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_infpart));
     SX_TRY(dev.get(static_cast<size_t>(nblk), &d_rpart));
     SX_TRY(dev.get(1, &d_st));
 
@@ -804,6 +823,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                          kl, ku, (long long)ndr);
             return SX_ERR_UNSUPPORTED;
         }
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: matching and band assembly done at %.1f ms\n", epochs, now() - t_begin);
         // ---------------------------------------------------------------- factor B11
         int32_t *d_trow = nullptr, *d_tcol = nullptr;
         double *d_tval = nullptr;
@@ -837,6 +857,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                     rowlist.erase(std::remove_if(rowlist.begin(), rowlist.end(), [&](const std::pair<int32_t, double> &e) { return rep[e.first] != 0; }),
                                   rowlist.end());
         }
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: band LU done at %.1f ms\n", epochs, now() - t_begin);
         std::fill(vstat.begin(), vstat.end(), 0);
         for (int64_t p = 0; p < m; ++p) {
             if (vstat[head[p]] == 1) {
@@ -1031,7 +1052,15 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             return SX_OK;
         };
         SX_TRY(load_slots(0, varJ));
+        if (trace) {
+            SX_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "[sx_crossover_band] epoch %d: basic solution and slots done at %.1f ms\n", epochs, now() - t_begin);
+        }
         SX_TRY(build_cols(0, nJ, 0));
+        if (trace) {
+            SX_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "[sx_crossover_band] epoch %d: tableau columns (FTRAN of %lld) done at %.1f ms\n", epochs, (long long)nJ, now() - t_begin);
+        }
         TbState hst{};
         hst.max_iter = max_iter - tot_iters;
         hst.cap_eta = EPOCH;
@@ -1045,16 +1074,16 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                     static_cast<double>(m) * capJ * 8e-9, now() - t_begin);
         // ---------------------------------------------------------------- the simplex on the tracked columns
         auto one_pivot = [&]() {
-            hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_part);
-            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_part, d_st);
-            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, d_T, d_g, d_st, d_d1);
+            hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
+            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_infpart, d_st);
+            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_infpart, d_st, d_d1);
             hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
             hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part);
-            hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st);
+            hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
             hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(1), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
             hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_st, d_rowbuf);
-            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st);
+            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, d_varJ, d_xJ, d_lJ, d_uJ,
                                d_cJ, d_statJ, d_eta_r, d_st);
         };
@@ -1071,8 +1100,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                     if (hst.status != 0) break;
                 }
             } else { // nothing tracked: only the state of the basic variables decides the phase
-                hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_part);
-                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_part, d_st);
+                hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
+                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_infpart, d_st);
                 SX_HIP(hipMemcpyAsync(&hst, d_st, sizeof(hst), hipMemcpyDeviceToHost, s));
                 SX_HIP(hipStreamSynchronize(s));
                 hst.status = 1;
