@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 struct sx_bandlu {
     sx_ctx *ctx = nullptr;
@@ -32,6 +33,7 @@ struct sx_bandlu {
     int32_t *replaced = nullptr; // [n] 1: column j was replaced by a unit vector
     int32_t *err = nullptr;      // [1] scatter found an entry outside the band
     bool factored = false;
+    std::vector<uint8_t> panel_swaps; // [panels] 1: the panel's factorisation swapped rows (host copy)
 };
 
 namespace {
@@ -422,6 +424,235 @@ __global__ __launch_bounds__(GB_T2) void k_gb_ltsolve(const double *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------- phase-split solves
+// The kernels above walk a panel column by column (32 steps, a barrier or two each: 27-112 us per launch).  For a
+// dense right-hand-side block the work of a panel splits into (i) a 32 x 32 triangular solve inside the panel -- the
+// panel's own block staged in LDS, one lane per right-hand side -- and (ii) one pass that combines the rows outside
+// the panel with the panel's 32 entries at once; no step depends on another inside (ii).  Forward / backward with L
+// need the panel to be free of row swaps (the host knows: ipiv), else the step-by-step kernels run.
+// LDS: w[R][8] | blk[32][33] | pa[32][8][8] | part[32][8]
+struct GbLds {
+    double *w, *blk, *pa, *part;
+    __device__ __forceinline__ GbLds(double *base, int R) {
+        w = base;
+        blk = w + static_cast<size_t>(R) * GB_CB;
+        pa = blk + GB_NB * (GB_NB + 1);
+        part = pa + GB_NB * 8 * GB_CB;
+    }
+};
+__host__ __device__ inline size_t gb_lds_bytes(int R) {
+    return sizeof(double) * (static_cast<size_t>(R) * GB_CB + GB_NB * (GB_NB + 1) + GB_NB * 8 * GB_CB + GB_NB * GB_CB);
+}
+
+// the panel's own 32 x 32 block of the factors (L strictly below the diagonal, U on and above) -> blk[r][c]
+__device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t j0, int ncol,
+                                              double *blk) {
+    for (int e = threadIdx.x; e < GB_NB * GB_NB; e += GB_T2) {
+        const int r = e / GB_NB, c = e % GB_NB;
+        double v = 0.0;
+        if (r < ncol && c < ncol && r - c <= kl && c - r <= ku + kl)
+            v = ab[static_cast<size_t>(kl + ku + r - c) + static_cast<size_t>(j0 + c) * ldab];
+        blk[r * (GB_NB + 1) + c] = v;
+    }
+}
+
+// U x = b, panel j0: rows i0 = max(0, j0 - ku - kl) .. j0 + ncol - 1
+__global__ __launch_bounds__(GB_T2) void k_gb_usolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                      int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double lds_raw[];
+    const int kw = ku + kl;
+    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
+    const int R = static_cast<int>(j0 + ncol - i0), top = static_cast<int>(j0 - i0);
+    GbLds L(lds_raw, R);
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k)
+        for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
+    gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    __syncthreads();
+    if (tid < GB_CB) { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c)
+        for (int c = ncol - 1; c >= 0; --c) {
+            double x = L.w[(top + c) * GB_CB + tid];
+            for (int cc = c + 1; cc < ncol; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * L.w[(top + cc) * GB_CB + tid];
+            L.w[(top + c) * GB_CB + tid] = x / L.blk[c * (GB_NB + 1) + c];
+        }
+    }
+    __syncthreads();
+    // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c
+    for (int rho = tid; rho < top; rho += GB_T2) {
+        const int64_t i = i0 + rho;
+        double acc[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
+        for (int c = 0; c < ncol; ++c) {
+            const int64_t j = j0 + c;
+            if (i >= j - kw) {
+                const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
+                if (a != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < GB_CB; ++k) acc[k] -= a * L.w[(top + c) * GB_CB + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
+    }
+    __syncthreads();
+    for (int k = 0; k < GB_CB; ++k)
+        if (t0 + k < ntgt)
+            for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+}
+
+// L forward for a panel WITHOUT row swaps: rows j0 .. j0 + R - 1
+__global__ __launch_bounds__(GB_T2) void k_gb_lsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                      int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double lds_raw[];
+    const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
+    GbLds L(lds_raw, R);
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k)
+        for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[j0 + rho + (t0 + k) * ldx] : 0.0;
+    gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    __syncthreads();
+    if (tid < GB_CB) { // the triangle, column by column: rows c' > c of the panel lose L(c', c) x_c
+        const int lim = (ncol < R) ? ncol : R;
+        for (int c = 0; c < lim; ++c) {
+            const double x = L.w[c * GB_CB + tid];
+            if (x != 0.0)
+                for (int cc = c + 1; cc < lim; ++cc) L.w[cc * GB_CB + tid] -= L.blk[cc * (GB_NB + 1) + c] * x;
+        }
+    }
+    __syncthreads();
+    for (int rho = ncol + tid; rho < R; rho += GB_T2) { // rows below the panel
+        double acc[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
+        for (int c = 0; c < ncol; ++c)
+            if (rho <= c + kl) {
+                const double a = ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab];
+                if (a != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < GB_CB; ++k) acc[k] -= a * L.w[c * GB_CB + k];
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
+    }
+    __syncthreads();
+    for (int k = 0; k < GB_CB; ++k)
+        if (t0 + k < ntgt)
+            for (int rho = tid; rho < R; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+}
+
+// U^T x = b, panel j0: x_j = (b_j - sum_{i < j} U(i, j) x_i) / U(j, j)
+__global__ __launch_bounds__(GB_T2) void k_gb_utsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                       int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double lds_raw[];
+    const int kw = ku + kl;
+    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
+    const int R = static_cast<int>(j0 + ncol - i0), top = static_cast<int>(j0 - i0);
+    GbLds L(lds_raw, R);
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k)
+        for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
+    gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    __syncthreads();
+    { // rows above the panel, all 32 columns at once: 8 lanes per column, each a strided share of the rows
+        const int c = tid >> 3, g = tid & 7;
+        double acc[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
+        if (c < ncol) {
+            const int64_t j = j0 + c;
+            const int64_t ilo = (j - kw > i0) ? j - kw : i0;
+            for (int64_t i = ilo + g; i < j0; i += 8) {
+                const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
+                if (a != 0.0) {
+                    const int rho = static_cast<int>(i - i0);
+#pragma unroll
+                    for (int k = 0; k < GB_CB; ++k) acc[k] += a * L.w[rho * GB_CB + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) L.pa[(c * 8 + g) * GB_CB + k] = acc[k];
+    }
+    __syncthreads();
+    {
+        const int c = tid >> 3, k = tid & 7;
+        double s = 0.0;
+        for (int g = 0; g < 8; ++g) s += L.pa[(c * 8 + g) * GB_CB + k];
+        L.part[c * GB_CB + k] = s;
+    }
+    __syncthreads();
+    if (tid < GB_CB) {
+        for (int c = 0; c < ncol; ++c) {
+            double x = L.w[(top + c) * GB_CB + tid] - L.part[c * GB_CB + tid];
+            for (int cc = 0; cc < c; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * L.w[(top + cc) * GB_CB + tid];
+            L.w[(top + c) * GB_CB + tid] = x / L.blk[c * (GB_NB + 1) + c];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < GB_CB; ++k)
+        if (t0 + k < ntgt)
+            for (int rho = top + tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+}
+
+// L^T backward for a panel WITHOUT row swaps: x_j -= sum_{i > j} L(i, j) x_i
+__global__ __launch_bounds__(GB_T2) void k_gb_ltsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                       int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double lds_raw[];
+    const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
+    GbLds L(lds_raw, R);
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    for (int k = 0; k < GB_CB; ++k)
+        for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[j0 + rho + (t0 + k) * ldx] : 0.0;
+    gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    __syncthreads();
+    { // rows below the panel, all columns at once
+        const int c = tid >> 3, g = tid & 7;
+        double acc[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
+        if (c < ncol) {
+            const int hi = (c + kl < R - 1) ? c + kl : R - 1;
+            for (int rho = ncol + g; rho <= hi; rho += 8) {
+                const double a = ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab];
+                if (a != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < GB_CB; ++k) acc[k] += a * L.w[rho * GB_CB + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) L.pa[(c * 8 + g) * GB_CB + k] = acc[k];
+    }
+    __syncthreads();
+    {
+        const int c = tid >> 3, k = tid & 7;
+        double s = 0.0;
+        for (int g = 0; g < 8; ++g) s += L.pa[(c * 8 + g) * GB_CB + k];
+        L.part[c * GB_CB + k] = s;
+    }
+    __syncthreads();
+    if (tid < GB_CB) {
+        const int lim = (ncol < R) ? ncol : R;
+        for (int c = lim - 1; c >= 0; --c) {
+            double x = L.w[c * GB_CB + tid] - L.part[c * GB_CB + tid];
+            for (int cc = c + 1; cc < lim; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * L.w[cc * GB_CB + tid];
+            L.w[c * GB_CB + tid] = x;
+        }
+    }
+    __syncthreads();
+    const int lim = (ncol < R) ? ncol : R;
+    for (int k = 0; k < GB_CB; ++k)
+        if (t0 + k < ntgt)
+            for (int rho = tid; rho < lim; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+}
+
 } // namespace
 
 SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
@@ -430,8 +661,7 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
     SX_REQUIRE(out && n > 0 && kl >= 0 && ku >= 0 && nnz >= 0, "bad argument");
     SX_REQUIRE(nnz == 0 || (row && col && val), "NULL triplets");
     SX_REQUIRE(static_cast<int64_t>(kl) + GB_NB <= 1536, "band too wide for the panel kernel (kl + 32 > 1536 rows)");
-    const size_t lds = static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double);
-    SX_REQUIRE(lds <= 150 * 1024, "band too wide for the solve kernels' LDS block (kl + ku + 32 > 2400 rows)");
+    SX_REQUIRE(gb_lds_bytes(kl + ku + GB_NB) <= 150 * 1024, "band too wide for the solve kernels' LDS block (kl + ku + 32 > 1950 rows)");
     sx_bandlu *h = new (std::nothrow) sx_bandlu();
     SX_REQUIRE(h != nullptr, "out of host memory");
     h->ctx = ctx;
@@ -462,6 +692,10 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_usolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_utsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_ltsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_usolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_lsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_utsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_ltsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     }
     SX_HIP(hipMemsetAsync(h->ab, 0, bytes, s));
     SX_HIP(hipMemsetAsync(h->ipiv, 0, sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4), s));
@@ -522,10 +756,14 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
     }
     SX_HIP(hipGetLastError());
     h->factored = true;
-    std::vector<int32_t> rep(static_cast<size_t>(n));
+    std::vector<int32_t> rep(static_cast<size_t>(n)), piv(static_cast<size_t>(n));
     SX_HIP(hipMemcpyAsync(rep.data(), h->replaced, sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
-    if (ipiv_host) SX_HIP(hipMemcpyAsync(ipiv_host, h->ipiv, sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
+    SX_HIP(hipMemcpyAsync(piv.data(), h->ipiv, sizeof(int32_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
+    if (ipiv_host) std::memcpy(ipiv_host, piv.data(), sizeof(int32_t) * static_cast<size_t>(n));
+    h->panel_swaps.assign(static_cast<size_t>((n + GB_NB - 1) / GB_NB), 0);
+    for (int64_t j = 0; j < n; ++j)
+        if (piv[static_cast<size_t>(j)] != j) h->panel_swaps[static_cast<size_t>(j / GB_NB)] = 1;
     int64_t cnt = 0;
     for (int64_t j = 0; j < n; ++j) cnt += rep[static_cast<size_t>(j)] != 0;
     if (n_replaced_out) *n_replaced_out = cnt;
@@ -547,30 +785,45 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     const unsigned grid = static_cast<unsigned>((nrhs + GB_CB - 1) / GB_CB);
     const int64_t npanel = (n + GB_NB - 1) / GB_NB;
     const size_t lds_l = static_cast<size_t>(kl + GB_NB) * GB_CB * sizeof(double);
-    const size_t lds_u = static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double);
+    const size_t lds_l2 = gb_lds_bytes(kl + GB_NB), lds_u2 = gb_lds_bytes(kl + ku + GB_NB);
+    static const bool slow = getenv("SX_BANDLU_STEPWISE") != nullptr; // the step-by-step kernels everywhere (A/B runs, tests)
     if (!trans) {
         for (int64_t p = 0; p < npanel; ++p) {
             const int64_t j0 = p * GB_NB;
             const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            hipLaunchKernelGGL((k_gb_apply<false>), dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv,
-                               0, nrhs, X, ldx);
+            if (slow || h->panel_swaps[static_cast<size_t>(p)])
+                hipLaunchKernelGGL((k_gb_apply<false>), dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv,
+                                   0, nrhs, X, ldx);
+            else
+                hipLaunchKernelGGL(k_gb_lsolve2, dim3(grid), dim3(GB_T2), lds_l2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
         }
         for (int64_t p = npanel - 1; p >= 0; --p) {
             const int64_t j0 = p * GB_NB;
             const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            hipLaunchKernelGGL(k_gb_usolve, dim3(grid), dim3(GB_T2), lds_u, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+            if (slow)
+                hipLaunchKernelGGL(k_gb_usolve, dim3(grid), dim3(GB_T2), static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double), s,
+                                   h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+            else
+                hipLaunchKernelGGL(k_gb_usolve2, dim3(grid), dim3(GB_T2), lds_u2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
         }
     } else {
         for (int64_t p = 0; p < npanel; ++p) {
             const int64_t j0 = p * GB_NB;
             const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            hipLaunchKernelGGL(k_gb_utsolve, dim3(grid), dim3(GB_T2), lds_u, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+            if (slow)
+                hipLaunchKernelGGL(k_gb_utsolve, dim3(grid), dim3(GB_T2), static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double), s,
+                                   h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
+            else
+                hipLaunchKernelGGL(k_gb_utsolve2, dim3(grid), dim3(GB_T2), lds_u2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
         }
         for (int64_t p = npanel - 1; p >= 0; --p) {
             const int64_t j0 = p * GB_NB;
             const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            hipLaunchKernelGGL(k_gb_ltsolve, dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, nrhs, X,
-                               ldx);
+            if (slow || h->panel_swaps[static_cast<size_t>(p)])
+                hipLaunchKernelGGL(k_gb_ltsolve, dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, nrhs, X,
+                                   ldx);
+            else
+                hipLaunchKernelGGL(k_gb_ltsolve2, dim3(grid), dim3(GB_T2), lds_l2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
         }
     }
     SX_HIP(hipGetLastError());

@@ -29,6 +29,7 @@ namespace {
 constexpr int TB_WG = 256;
 constexpr int TB_SUP = 3, TB_LOW = 1, TB_UPP = 2; // status of a tracked non-basic column
 constexpr double TB_PIV = 1e-7;                   // smallest |alpha| the ratio test accepts
+constexpr double TB_DROP = 1e-14;                 // tableau entries below this become exact zeros (keeps B^-1 A_J local)
 
 struct TbState {
     long long iters, max_iter, n_eta, cap_eta, pivots, flips, degen;
@@ -137,16 +138,21 @@ __global__ __launch_bounds__(TB_WG) void k_tb_infeas(int64_t m, const double *__
     }
 }
 
-__global__ void k_tb_phase(int nblk, const double *__restrict__ part, TbState *st) {
+__global__ __launch_bounds__(TB_WG) void k_tb_phase(int nblk, const double *__restrict__ part, TbState *st) {
+    __shared__ double sm[4];
     if (st->status != 0) return;
     double cnt = 0.0, sum = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = threadIdx.x; k < nblk; k += TB_WG) { // (counts are small integers: any order gives the same sum)
         cnt += part[2 * k];
         sum += part[2 * k + 1];
     }
-    st->n_inf = static_cast<int>(cnt);
-    st->sum_inf = sum;
-    st->phase = cnt > 0.0 ? 1 : 2;
+    cnt = tb_block_sum(cnt, sm);
+    sum = tb_block_sum(sum, sm);
+    if (threadIdx.x == 0) {
+        st->n_inf = static_cast<int>(cnt);
+        st->sum_inf = sum;
+        st->phase = cnt > 0.0 ? 1 : 2;
+    }
 }
 
 // phase 1 only: d1[s] = - sum_p g[p] T[p, s].  Few basic variables are infeasible behind a first-order point, so
@@ -405,13 +411,44 @@ __global__ __launch_bounds__(TB_WG) void k_tb_ratio(int64_t m, const double *__r
     }
 }
 
-__global__ void k_tb_decide(int nblk, const TbPart *__restrict__ part, const double *__restrict__ xJ,
-                            const double *__restrict__ lJ, const double *__restrict__ uJ, const int32_t *__restrict__ statJ,
-                            TbState *st) {
+__global__ __launch_bounds__(TB_WG) void k_tb_decide(int nblk, const TbPart *__restrict__ part, const double *__restrict__ xJ,
+                                                     const double *__restrict__ lJ, const double *__restrict__ uJ,
+                                                     const int32_t *__restrict__ statJ, TbState *st) {
+    __shared__ double sa_[TB_WG], st_[TB_WG];
+    __shared__ int sp_[TB_WG], sh_[TB_WG];
     if (st->status != 0) return;
-    TbPart b = part[0];
-    for (int k = 1; k < nblk; ++k)
-        if (part[k].a > b.a) b = part[k];
+    // largest pivot among the rows pass 2 admitted; ties to the smaller position (blocks are in position order)
+    TbPart b;
+    b.a = -1.0;
+    b.t = INFINITY;
+    b.p = 0x7fffffff;
+    b.hit = 0;
+    for (int k = threadIdx.x; k < nblk; k += TB_WG) {
+        const TbPart o = part[k];
+        if (o.a > b.a || (o.a == b.a && o.p < b.p)) b = o;
+    }
+    sa_[threadIdx.x] = b.a;
+    st_[threadIdx.x] = b.t;
+    sp_[threadIdx.x] = b.p;
+    sh_[threadIdx.x] = b.hit;
+    __syncthreads();
+    for (int o = TB_WG / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const int j = threadIdx.x + o;
+            if (sa_[j] > sa_[threadIdx.x] || (sa_[j] == sa_[threadIdx.x] && sp_[j] < sp_[threadIdx.x])) {
+                sa_[threadIdx.x] = sa_[j];
+                st_[threadIdx.x] = st_[j];
+                sp_[threadIdx.x] = sp_[j];
+                sh_[threadIdx.x] = sh_[j];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    b.a = sa_[0];
+    b.t = st_[0];
+    b.p = sp_[0];
+    b.hit = sh_[0];
     if (b.a < 0.0) b.t = INFINITY; // no row blocks
     const int q = st->q;
     // the entering column's own way to its other bound
@@ -469,12 +506,13 @@ __global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, int64_t nJ, doub
         const double f = a / ar;
         for (int64_t s = s0; s < s1; ++s) {
             if (s == q) {
-                T[static_cast<size_t>(s) * m + p] = -f;
+                T[static_cast<size_t>(s) * m + p] = fabs(f) < TB_DROP ? 0.0 : -f;
             } else {
                 const double rb_ = rowbuf[s];
                 if (rb_ != 0.0) {
                     double *t = T + static_cast<size_t>(s) * m + p;
-                    *t = *t - f * rb_;
+                    const double v = *t - f * rb_;
+                    *t = fabs(v) < TB_DROP ? 0.0 : v; // (a tail of 1e-20s would spread the columns' supports over the whole matrix)
                 }
             }
         }
@@ -901,7 +939,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             // the eta file takes what is left (up to 20,000 basis changes)
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
             if (!getenv("SX_BAND_EPOCH"))
-                EPOCH = std::min<int64_t>(20000, std::max<int64_t>(256, static_cast<int64_t>(0.8 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m))) - 1));
+                EPOCH = std::min<int64_t>(std::min<int64_t>(20000, 4 * nJ + 4096),
+                                          std::max<int64_t>(256, static_cast<int64_t>(0.8 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m))) - 1));
             SX_TRY(dev.get(static_cast<size_t>(m) * (EPOCH + 1), &d_eta));
             SX_TRY(dev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
         }
@@ -1045,7 +1084,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_HIP(hipMemsetAsync(W, 0, sizeof(double) * static_cast<size_t>(m) * k, s));
             hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(k)), dim3(TB_WG), 0, s, k, d_varJ + s0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, W, m);
             SX_TRY(ftran_cols(W, k, n_eta_now));
-            hipLaunchKernelGGL(k_tb_drop, dim3(gridof(m * k)), dim3(TB_WG), 0, s, m * k, W, 1e-13);
+            hipLaunchKernelGGL(k_tb_drop, dim3(gridof(m * k)), dim3(TB_WG), 0, s, m * k, W, 10.0 * TB_DROP);
             // reduced costs of the new columns under the current basis: d = c_J - c_B^T T
             hipLaunchKernelGGL(k_tb_coldot, dim3(static_cast<unsigned>(k)), dim3(TB_WG), 0, s, m, W, d_cB, d_cJ + s0, d_dJ + s0);
             SX_HIP(hipGetLastError());
@@ -1075,13 +1114,13 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         // ---------------------------------------------------------------- the simplex on the tracked columns
         auto one_pivot = [&]() {
             hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
-            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_infpart, d_st);
+            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st);
             hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_infpart, d_st, d_d1);
             hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
             hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part);
             hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
-            hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(1), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
+            hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(TB_WG), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
             hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_st, d_rowbuf);
             hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, d_varJ, d_xJ, d_lJ, d_uJ,
@@ -1101,7 +1140,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 }
             } else { // nothing tracked: only the state of the basic variables decides the phase
                 hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
-                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(1), 0, s, nblk, d_infpart, d_st);
+                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st);
                 SX_HIP(hipMemcpyAsync(&hst, d_st, sizeof(hst), hipMemcpyDeviceToHost, s));
                 SX_HIP(hipStreamSynchronize(s));
                 hst.status = 1;

@@ -519,7 +519,8 @@ SX_API int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const d
     // ---- one hipGraph per period of 64 iterations (+ check, decision, restart)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    bool use_graph = ctx->opt_graph != 0;
+    bool use_graph = ctx->opt_graph != 0 && getenv("SX_NO_GRAPH") == nullptr &&
+                     getenv("ROCP_TOOL_LIBRARIES") == nullptr; // (rocprofv3 --kernel-trace faults on graph replay: profiles/r03/hipgraph_rocprofv3.md)
     if (use_graph) {
         SX_HIP(hipStreamSynchronize(s));
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
