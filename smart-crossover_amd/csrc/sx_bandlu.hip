@@ -8,14 +8,16 @@
 //             (the first kl rows of every column are room for the fill partial pivoting creates);
 //   factor    panels of 32 columns.  k_gb_panel: ONE workgroup holds the panel's kl + 32 rows in registers (a row
 //             per lane, 32 doubles), per column: arg-max over the lanes -> row swap through LDS -> scale -> rank-one
-//             update in registers.  k_gb_apply: the columns to the right (<= ku + kl + 32 of them), 8 per workgroup
-//             in LDS: the panel's 32 row swaps, then 32 elimination steps with the multipliers read from L2.
+//             update in registers (bands of up to 160 sub-diagonals: ONE wave, three rows per lane).  k_gb_trail2: the
+//             columns to the right (<= ku + kl + 32 of them), 8 per workgroup in LDS: a 32 x 32 triangle + one
+//             combining pass, or -- when the panel swapped rows -- swap and elimination column by column.
 //             A column without a usable pivot is REPLACED in place by the unit vector of the row on its diagonal
 //             (pivot 1, no multipliers): the caller learns which columns were replaced and treats those rows as
 //             covered by their logical variable -- a singular or ill-conditioned guess of a basis is repaired
 //             instead of failing the factorisation;
-//   solves    the same panel kernels run over a dense right-hand-side block (forward), a mirror pair for U, and
-//             the transposed pair; right-hand sides 8 per workgroup, so hundreds of them cost what one costs.
+//   solves    ONE launch per solve: right-hand sides 8 per workgroup, every workgroup walks all panels by itself
+//             (forward, then backward; both orientations); per panel a 32 x 32 triangle in LDS + one combining
+//             pass, or -- for a panel whose factorisation swapped rows -- the column-by-column step.
 //
 // fp64, FMA contraction off like the rest of the library.  No atomics; a fixed arithmetic order per entry.
 #include "sx_internal.h"
@@ -32,6 +34,7 @@ struct sx_bandlu {
     int32_t *ipiv = nullptr;     // [n] global row swapped with j at step j
     int32_t *replaced = nullptr; // [n] 1: column j was replaced by a unit vector
     int32_t *err = nullptr;      // [1] scatter found an entry outside the band
+    uint8_t *d_swaps = nullptr;  // [panels] 1: the panel's factorisation swapped rows
     bool factored = false;
     std::vector<uint8_t> panel_swaps; // [panels] 1: the panel's factorisation swapped rows (host copy)
 };
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int lda
 // matrix itself (stored rows [j - ku - kl, j + kl]); otherwise columns of a dense block X (ldx).
 // LDS holds rows j0 .. j0 + R - 1 of the targets; the panel's swaps, then its elimination steps.
 template <bool BAND>
-__global__ __launch_bounds__(GB_T2) void k_gb_apply(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0,
+__device__ __forceinline__ void gb_apply_body(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0,
                                                     int ncol, const int32_t *__restrict__ ipiv, int64_t jt0, int64_t ntgt,
                                                     double *__restrict__ X, int64_t ldx) {
     extern __shared__ double w[]; // [R][GB_CB]
@@ -293,95 +296,9 @@ __global__ __launch_bounds__(GB_T2) void k_gb_apply(double *__restrict__ ab, int
     }
 }
 
-// ------------------------------------------------------------------------------------------- U x = b (backward)
-// Panel columns j0 .. j0 + ncol - 1, rows i0 = max(0, j0 - ku - kl) .. j0 + ncol - 1 of GB_CB right-hand sides.
-__global__ __launch_bounds__(GB_T2) void k_gb_usolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
-                                                     int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X,
-                                                     int64_t ldx) {
-    extern __shared__ double w[];
-    const int tid = threadIdx.x;
-    const int kw = ku + kl;
-    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
-    const int R = static_cast<int>(j0 + ncol - i0);
-    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
-    for (int k = 0; k < GB_CB; ++k) {
-        const int64_t t = t0 + k;
-        for (int rho = tid; rho < R; rho += GB_T2) w[rho * GB_CB + k] = (t < ntgt) ? X[i0 + rho + t * ldx] : 0.0;
-    }
-    __syncthreads();
-    for (int c = ncol - 1; c >= 0; --c) {
-        const int64_t j = j0 + c;
-        const int rj = static_cast<int>(j - i0);
-        const double d = ab[static_cast<size_t>(kl + ku) + static_cast<size_t>(j) * ldab];
-        if (tid < GB_CB) w[rj * GB_CB + tid] = w[rj * GB_CB + tid] / d;
-        __syncthreads();
-        double u[GB_CB];
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) u[k] = w[rj * GB_CB + k];
-        const int64_t ilo = (j - kw > i0) ? j - kw : i0;
-        for (int64_t i = ilo + tid; i < j; i += GB_T2) {
-            const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
-            if (a != 0.0) {
-                const int rho = static_cast<int>(i - i0);
-#pragma unroll
-                for (int k = 0; k < GB_CB; ++k) w[rho * GB_CB + k] = w[rho * GB_CB + k] - a * u[k];
-            }
-        }
-        __syncthreads();
-    }
-    for (int k = 0; k < GB_CB; ++k) {
-        const int64_t t = t0 + k;
-        if (t >= ntgt) continue;
-        for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + t * ldx] = w[rho * GB_CB + k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------- U^T x = b (forward)
-// x_j = (b_j - sum_{i<j} U(i, j) x_i) / U(j, j): rows i0 .. j0 + ncol - 1 in LDS; per column a dot product over
-// the lanes (32 lanes per right-hand side), reduced through LDS.
-__global__ __launch_bounds__(GB_T2) void k_gb_utsolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
-                                                      int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X,
-                                                      int64_t ldx) {
-    extern __shared__ double w[];
-    __shared__ double red[GB_T2];
-    const int tid = threadIdx.x;
-    const int kw = ku + kl;
-    const int64_t i0 = (j0 - kw > 0) ? j0 - kw : 0;
-    const int R = static_cast<int>(j0 + ncol - i0);
-    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
-    for (int k = 0; k < GB_CB; ++k) {
-        const int64_t t = t0 + k;
-        for (int rho = tid; rho < R; rho += GB_T2) w[rho * GB_CB + k] = (t < ntgt) ? X[i0 + rho + t * ldx] : 0.0;
-    }
-    __syncthreads();
-    const int k = tid & (GB_CB - 1), lane = tid / GB_CB; // 32 lanes per right-hand side
-    constexpr int LPT = GB_T2 / GB_CB;
-    for (int c = 0; c < ncol; ++c) {
-        const int64_t j = j0 + c;
-        const int64_t ilo = (j - kw > i0) ? j - kw : i0;
-        double s = 0.0;
-        for (int64_t i = ilo + lane; i < j; i += LPT)
-            s += ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] * w[static_cast<int>(i - i0) * GB_CB + k];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < GB_CB) {
-            double acc = 0.0;
-            for (int q = 0; q < LPT; ++q) acc += red[q * GB_CB + tid];
-            const int rj = static_cast<int>(j - i0);
-            w[rj * GB_CB + tid] = (w[rj * GB_CB + tid] - acc) / ab[static_cast<size_t>(kl + ku) + static_cast<size_t>(j) * ldab];
-        }
-        __syncthreads();
-    }
-    for (int kk = 0; kk < GB_CB; ++kk) {
-        const int64_t t = t0 + kk;
-        if (t >= ntgt) continue;
-        for (int rho = static_cast<int>(j0 - i0) + tid; rho < R; rho += GB_T2) X[i0 + rho + t * ldx] = w[rho * GB_CB + kk];
-    }
-}
-
 // ------------------------------------------------------------------------------------------- L^T with swaps (backward)
 // for j descending: x_j -= sum_{i=j+1..j+kl} L(i, j) x_i; swap x_j <-> x_ipiv(j).  Rows j0 .. j0 + R - 1 in LDS.
-__global__ __launch_bounds__(GB_T2) void k_gb_ltsolve(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+__device__ __forceinline__ void gb_ltsolve_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                       int64_t j0, int ncol, const int32_t *__restrict__ ipiv, int64_t ntgt,
                                                       double *__restrict__ X, int64_t ldx) {
     extern __shared__ double w[];
@@ -457,7 +374,7 @@ __device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int
 }
 
 // U x = b, panel j0: rows i0 = max(0, j0 - ku - kl) .. j0 + ncol - 1
-__global__ __launch_bounds__(GB_T2) void k_gb_usolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+__device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                       int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
     extern __shared__ double lds_raw[];
     const int kw = ku + kl;
@@ -503,16 +420,32 @@ __global__ __launch_bounds__(GB_T2) void k_gb_usolve2(const double *__restrict__
             for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
 }
 
-// L forward for a panel WITHOUT row swaps: rows j0 .. j0 + R - 1
-__global__ __launch_bounds__(GB_T2) void k_gb_lsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
-                                                      int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
+// L forward for a panel WITHOUT row swaps: rows j0 .. j0 + R - 1.
+// BAND: the targets are the band matrix' own columns jt0 + t to the right of the panel (factorisation).
+template <bool BAND>
+__device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0, int ncol,
+                                                int64_t jt0, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
     extern __shared__ double lds_raw[];
     const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
     GbLds L(lds_raw, R);
     const int tid = threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
-    for (int k = 0; k < GB_CB; ++k)
-        for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[j0 + rho + (t0 + k) * ldx] : 0.0;
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        for (int rho = tid; rho < R; rho += GB_T2) {
+            double x = 0.0;
+            if (t < ntgt) {
+                const int64_t i = j0 + rho;
+                if (BAND) {
+                    const int64_t j = jt0 + t;
+                    if (i >= j - ku - kl && i <= j + kl) x = AB(ab, ldab, kl, ku, i, j);
+                } else {
+                    x = X[i + t * ldx];
+                }
+            }
+            L.w[rho * GB_CB + k] = x;
+        }
+    }
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
     __syncthreads();
     if (tid < GB_CB) { // the triangle, column by column: rows c' > c of the panel lose L(c', c) x_c
@@ -540,13 +473,23 @@ __global__ __launch_bounds__(GB_T2) void k_gb_lsolve2(const double *__restrict__
         for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
     }
     __syncthreads();
-    for (int k = 0; k < GB_CB; ++k)
-        if (t0 + k < ntgt)
-            for (int rho = tid; rho < R; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+    for (int k = 0; k < GB_CB; ++k) {
+        const int64_t t = t0 + k;
+        if (t >= ntgt) continue;
+        for (int rho = tid; rho < R; rho += GB_T2) {
+            const int64_t i = j0 + rho;
+            if (BAND) {
+                const int64_t j = jt0 + t;
+                if (i >= j - ku - kl && i <= j + kl) AB(ab, ldab, kl, ku, i, j) = L.w[rho * GB_CB + k];
+            } else {
+                X[i + t * ldx] = L.w[rho * GB_CB + k];
+            }
+        }
+    }
 }
 
 // U^T x = b, panel j0: x_j = (b_j - sum_{i < j} U(i, j) x_i) / U(j, j)
-__global__ __launch_bounds__(GB_T2) void k_gb_utsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+__device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                        int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
     extern __shared__ double lds_raw[];
     const int kw = ku + kl;
@@ -601,7 +544,7 @@ __global__ __launch_bounds__(GB_T2) void k_gb_utsolve2(const double *__restrict_
 }
 
 // L^T backward for a panel WITHOUT row swaps: x_j -= sum_{i > j} L(i, j) x_i
-__global__ __launch_bounds__(GB_T2) void k_gb_ltsolve2(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+__device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                        int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
     extern __shared__ double lds_raw[];
     const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
@@ -653,6 +596,58 @@ __global__ __launch_bounds__(GB_T2) void k_gb_ltsolve2(const double *__restrict_
             for (int rho = tid; rho < lim; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
 }
 
+// ------------------------------------------------------------------------------------------- launch wrappers
+// the factorisation's update of the columns to the right of a panel that swapped no rows
+// (which it did the panel kernel has just decided: the branch is taken on the device, uniformly)
+__global__ __launch_bounds__(GB_T2) void k_gb_trail2(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0, int ncol,
+                                                     const int32_t *__restrict__ ipiv, int64_t jt0, int64_t ntgt) {
+    __shared__ int swapped;
+    if (threadIdx.x == 0) swapped = 0;
+    __syncthreads();
+    if (threadIdx.x < ncol && ipiv[j0 + threadIdx.x] != j0 + threadIdx.x) swapped = 1; // (every writer stores 1)
+    __syncthreads();
+    if (swapped) gb_apply_body<true>(ab, ldab, kl, ku, n, j0, ncol, ipiv, jt0, ntgt, nullptr, 0);
+    else gb_lsolve2_body<true>(ab, ldab, kl, ku, n, j0, ncol, jt0, ntgt, nullptr, 0);
+}
+
+// A whole solve in ONE launch: the right-hand sides of different workgroups never meet, so every workgroup walks
+// all panels by itself (forward, then backward) -- no launch per panel, the factors stream through L2.
+// trans = 0: A x = b (L with the row swaps, then U); 1: A^T x = b (U^T, then L^T with the swaps).
+__global__ __launch_bounds__(GB_T2) void k_gb_solve_loop(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                         const int32_t *__restrict__ ipiv, const uint8_t *__restrict__ swaps,
+                                                         int64_t ntgt, double *__restrict__ X, int64_t ldx, int trans, int stepwise) {
+    const int64_t npanel = (n + GB_NB - 1) / GB_NB;
+    if (!trans) {
+        for (int64_t p = 0; p < npanel; ++p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            if (stepwise || swaps[p]) gb_apply_body<false>(ab, ldab, kl, ku, n, j0, ncol, ipiv, 0, ntgt, X, ldx);
+            else gb_lsolve2_body<false>(ab, ldab, kl, ku, n, j0, ncol, 0, ntgt, X, ldx);
+            __syncthreads();
+        }
+        for (int64_t p = npanel - 1; p >= 0; --p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            gb_usolve2_body(ab, ldab, kl, ku, n, j0, ncol, ntgt, X, ldx);
+            __syncthreads();
+        }
+    } else {
+        for (int64_t p = 0; p < npanel; ++p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            gb_utsolve2_body(ab, ldab, kl, ku, n, j0, ncol, ntgt, X, ldx);
+            __syncthreads();
+        }
+        for (int64_t p = npanel - 1; p >= 0; --p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            if (stepwise || swaps[p]) gb_ltsolve_body(ab, ldab, kl, ku, n, j0, ncol, ipiv, ntgt, X, ldx);
+            else gb_ltsolve2_body(ab, ldab, kl, ku, n, j0, ncol, ntgt, X, ldx);
+            __syncthreads();
+        }
+    }
+}
+
 } // namespace
 
 SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
@@ -675,6 +670,7 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
             if (h) {
                 (void)hipFree(h->ab);
                 (void)hipFree(h->ipiv);
+                (void)hipFree(h->d_swaps);
                 delete h;
             }
         }
@@ -682,20 +678,14 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
     const size_t bytes = sizeof(double) * static_cast<size_t>(h->ldab) * static_cast<size_t>(n);
     SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ab), bytes));
     SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4)));
+    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_swaps), static_cast<size_t>((n + GB_NB - 1) / GB_NB) + 8));
     h->replaced = h->ipiv + n;
     h->err = h->replaced + n;
     hipStream_t s = ctx->stream;
     {   // the LDS blocks of the apply / solve kernels pass the 64 KiB a launch gets by default
         const int cap = 150 * 1024;
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_usolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_utsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_ltsolve), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_usolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_lsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_utsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_ltsolve2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_solve_loop), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_trail2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     }
     SX_HIP(hipMemsetAsync(h->ab, 0, bytes, s));
     SX_HIP(hipMemsetAsync(h->ipiv, 0, sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4), s));
@@ -718,6 +708,7 @@ SX_API int sx_bandlu_destroy(sx_bandlu *h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     (void)hipFree(h->ab);
     (void)hipFree(h->ipiv);
+    (void)hipFree(h->d_swaps);
     delete h;
     return SX_OK;
 }
@@ -734,7 +725,19 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
     const int rows = kl + GB_NB; // rows of a panel: a row per lane and register slot
     for (int64_t j0 = 0; j0 < n; j0 += GB_NB) {
         const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-        if (rows <= 512)
+        if (rows <= 64) // narrow bands: ONE wave, up to three rows per lane -- the barriers of a step cost nothing
+            hipLaunchKernelGGL((k_gb_panel<64, 1>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
+                               h->replaced);
+        else if (rows <= 128)
+            hipLaunchKernelGGL((k_gb_panel<64, 2>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
+                               h->replaced);
+        else if (rows <= 192)
+            hipLaunchKernelGGL((k_gb_panel<64, 3>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
+                               h->replaced);
+        else if (rows <= 256)
+            hipLaunchKernelGGL((k_gb_panel<256, 1>), dim3(1), dim3(256), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
+                               h->replaced);
+        else if (rows <= 512)
             hipLaunchKernelGGL((k_gb_panel<512, 1>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
                                h->ipiv, h->replaced);
         else if (rows <= 1024)
@@ -749,9 +752,8 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
         const int64_t ntgt = jt1 - jt0;
         if (ntgt > 0) {
             const int R = static_cast<int>(std::min<int64_t>(n - j0, static_cast<int64_t>(kl) + ncol));
-            const size_t lds = static_cast<size_t>(R) * GB_CB * sizeof(double);
-            hipLaunchKernelGGL((k_gb_apply<true>), dim3(static_cast<unsigned>((ntgt + GB_CB - 1) / GB_CB)), dim3(GB_T2), lds, s,
-                               h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, jt0, ntgt, nullptr, 0);
+            hipLaunchKernelGGL(k_gb_trail2, dim3(static_cast<unsigned>((ntgt + GB_CB - 1) / GB_CB)), dim3(GB_T2), gb_lds_bytes(R), s, h->ab,
+                               h->ldab, kl, ku, n, j0, ncol, h->ipiv, jt0, ntgt);
         }
     }
     SX_HIP(hipGetLastError());
@@ -764,6 +766,8 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
     h->panel_swaps.assign(static_cast<size_t>((n + GB_NB - 1) / GB_NB), 0);
     for (int64_t j = 0; j < n; ++j)
         if (piv[static_cast<size_t>(j)] != j) h->panel_swaps[static_cast<size_t>(j / GB_NB)] = 1;
+    SX_HIP(hipMemcpyAsync(h->d_swaps, h->panel_swaps.data(), h->panel_swaps.size(), hipMemcpyHostToDevice, s));
+    SX_HIP(hipStreamSynchronize(s));
     int64_t cnt = 0;
     for (int64_t j = 0; j < n; ++j) cnt += rep[static_cast<size_t>(j)] != 0;
     if (n_replaced_out) *n_replaced_out = cnt;
@@ -784,48 +788,10 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     const int64_t n = h->n;
     const unsigned grid = static_cast<unsigned>((nrhs + GB_CB - 1) / GB_CB);
     const int64_t npanel = (n + GB_NB - 1) / GB_NB;
-    const size_t lds_l = static_cast<size_t>(kl + GB_NB) * GB_CB * sizeof(double);
-    const size_t lds_l2 = gb_lds_bytes(kl + GB_NB), lds_u2 = gb_lds_bytes(kl + ku + GB_NB);
-    static const bool slow = getenv("SX_BANDLU_STEPWISE") != nullptr; // the step-by-step kernels everywhere (A/B runs, tests)
-    if (!trans) {
-        for (int64_t p = 0; p < npanel; ++p) {
-            const int64_t j0 = p * GB_NB;
-            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            if (slow || h->panel_swaps[static_cast<size_t>(p)])
-                hipLaunchKernelGGL((k_gb_apply<false>), dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv,
-                                   0, nrhs, X, ldx);
-            else
-                hipLaunchKernelGGL(k_gb_lsolve2, dim3(grid), dim3(GB_T2), lds_l2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-        }
-        for (int64_t p = npanel - 1; p >= 0; --p) {
-            const int64_t j0 = p * GB_NB;
-            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            if (slow)
-                hipLaunchKernelGGL(k_gb_usolve, dim3(grid), dim3(GB_T2), static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double), s,
-                                   h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-            else
-                hipLaunchKernelGGL(k_gb_usolve2, dim3(grid), dim3(GB_T2), lds_u2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-        }
-    } else {
-        for (int64_t p = 0; p < npanel; ++p) {
-            const int64_t j0 = p * GB_NB;
-            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            if (slow)
-                hipLaunchKernelGGL(k_gb_utsolve, dim3(grid), dim3(GB_T2), static_cast<size_t>(kl + ku + GB_NB) * GB_CB * sizeof(double), s,
-                                   h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-            else
-                hipLaunchKernelGGL(k_gb_utsolve2, dim3(grid), dim3(GB_T2), lds_u2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-        }
-        for (int64_t p = npanel - 1; p >= 0; --p) {
-            const int64_t j0 = p * GB_NB;
-            const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-            if (slow || h->panel_swaps[static_cast<size_t>(p)])
-                hipLaunchKernelGGL(k_gb_ltsolve, dim3(grid), dim3(GB_T2), lds_l, s, h->ab, h->ldab, kl, ku, n, j0, ncol, h->ipiv, nrhs, X,
-                                   ldx);
-            else
-                hipLaunchKernelGGL(k_gb_ltsolve2, dim3(grid), dim3(GB_T2), lds_l2, s, h->ab, h->ldab, kl, ku, n, j0, ncol, nrhs, X, ldx);
-        }
-    }
+    static const bool slow = getenv("SX_BANDLU_STEPWISE") != nullptr; // the step-by-step panel bodies everywhere (A/B runs, tests)
+    (void)npanel;
+    hipLaunchKernelGGL(k_gb_solve_loop, dim3(grid), dim3(GB_T2), gb_lds_bytes(kl + ku + GB_NB), s, h->ab, h->ldab, kl, ku, n, h->ipiv,
+                       h->d_swaps, nrhs, X, ldx, trans ? 1 : 0, slow ? 1 : 0);
     SX_HIP(hipGetLastError());
     return SX_OK;
 }

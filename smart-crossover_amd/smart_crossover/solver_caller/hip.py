@@ -193,6 +193,8 @@ class HipCaller(SolverCaller):
                         self._res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_px, 0, 1e-7,
                                                        float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
                         self.solved_by = "crossover_band"
+                        if int(self._res.status) not in _STATUS and 8.0 * m * m < 1.2e11:
+                            self._res = None      # iteration limit / numerical trouble: the dense crossover may still do it
                     except NotImplementedError:
                         self._res = None          # no band structure: the dense crossover below
             if self._res is None:

@@ -7,6 +7,7 @@ sampled bit-exact comparisons (the oracle finishes these sizes in seconds, so mo
 """
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from conftest import bits_equal
 from oracle import lp_path as L

