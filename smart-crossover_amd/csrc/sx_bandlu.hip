@@ -8,7 +8,7 @@
 //             (the first kl rows of every column are room for the fill partial pivoting creates);
 //   factor    panels of 32 columns.  k_gb_panel: ONE workgroup holds the panel's kl + 32 rows in registers (a row
 //             per lane, 32 doubles), per column: arg-max over the lanes -> row swap through LDS -> scale -> rank-one
-//             update in registers (bands of up to 160 sub-diagonals: ONE wave, three rows per lane).  k_gb_trail2: the
+//             update in registers.  k_gb_trail2: the
 //             columns to the right (<= ku + kl + 32 of them), 8 per workgroup in LDS: a 32 x 32 triangle + one
 //             combining pass, or -- when the panel swapped rows -- swap and elimination column by column.
 //             A column without a usable pivot is REPLACED in place by the unit vector of the row on its diagonal
@@ -387,12 +387,22 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
     __syncthreads();
-    if (tid < GB_CB) { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c)
-        for (int c = ncol - 1; c >= 0; --c) {
-            double x = L.w[(top + c) * GB_CB + tid];
-            for (int cc = c + 1; cc < ncol; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * L.w[(top + cc) * GB_CB + tid];
-            L.w[(top + c) * GB_CB + tid] = x / L.blk[c * (GB_NB + 1) + c];
+    if (tid < GB_CB) { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c); the 32 unknowns in registers
+        double xs[GB_NB];
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] : 0.0;
+#pragma unroll
+        for (int c = GB_NB - 1; c >= 0; --c) {
+            if (c < ncol) {
+                double x = xs[c];
+#pragma unroll
+                for (int cc = c + 1; cc < GB_NB; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * xs[cc]; // (blk is zero beyond ncol)
+                xs[c] = x / L.blk[c * (GB_NB + 1) + c];
+            }
         }
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c)
+            if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
     }
     __syncthreads();
     // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c
@@ -401,15 +411,16 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
         double acc[GB_CB];
 #pragma unroll
         for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
-        for (int c = 0; c < ncol; ++c) {
-            const int64_t j = j0 + c;
-            if (i >= j - kw) {
-                const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
-                if (a != 0.0) {
+        double av[GB_NB]; // the row's 32 entries of U first (independent loads in flight together), then the arithmetic
 #pragma unroll
-                    for (int k = 0; k < GB_CB; ++k) acc[k] -= a * L.w[(top + c) * GB_CB + k];
-                }
-            }
+        for (int c = 0; c < GB_NB; ++c) {
+            const int64_t j = j0 + c;
+            av[c] = (c < ncol && i >= j - kw) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) {
+#pragma unroll
+            for (int k = 0; k < GB_CB; ++k) acc[k] -= av[c] * L.w[(top + c) * GB_CB + k];
         }
 #pragma unroll
         for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
@@ -448,27 +459,36 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
     }
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
     __syncthreads();
-    if (tid < GB_CB) { // the triangle, column by column: rows c' > c of the panel lose L(c', c) x_c
+    if (tid < GB_CB) { // the triangle: x_c = b_c - sum_{c' < c} L(c, c') x_c'; the 32 unknowns in registers
         const int lim = (ncol < R) ? ncol : R;
-        for (int c = 0; c < lim; ++c) {
-            const double x = L.w[c * GB_CB + tid];
-            if (x != 0.0)
-                for (int cc = c + 1; cc < lim; ++cc) L.w[cc * GB_CB + tid] -= L.blk[cc * (GB_NB + 1) + c] * x;
+        double xs[GB_NB];
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] : 0.0;
+#pragma unroll
+        for (int c = 1; c < GB_NB; ++c) {
+            double x = xs[c];
+#pragma unroll
+            for (int cc = 0; cc < c; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * xs[cc]; // (blk is zero outside the panel)
+            xs[c] = x;
         }
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c)
+            if (c < lim) L.w[c * GB_CB + tid] = xs[c];
     }
     __syncthreads();
     for (int rho = ncol + tid; rho < R; rho += GB_T2) { // rows below the panel
         double acc[GB_CB];
 #pragma unroll
         for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
-        for (int c = 0; c < ncol; ++c)
-            if (rho <= c + kl) {
-                const double a = ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab];
-                if (a != 0.0) {
+        double av[GB_NB];
 #pragma unroll
-                    for (int k = 0; k < GB_CB; ++k) acc[k] -= a * L.w[c * GB_CB + k];
-                }
-            }
+        for (int c = 0; c < GB_NB; ++c)
+            av[c] = (c < ncol && rho <= c + kl) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) {
+#pragma unroll
+            for (int k = 0; k < GB_CB; ++k) acc[k] -= av[c] * L.w[c * GB_CB + k];
+        }
 #pragma unroll
         for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
     }
@@ -510,12 +530,21 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
         if (c < ncol) {
             const int64_t j = j0 + c;
             const int64_t ilo = (j - kw > i0) ? j - kw : i0;
-            for (int64_t i = ilo + g; i < j0; i += 8) {
-                const double a = ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
-                if (a != 0.0) {
-                    const int rho = static_cast<int>(i - i0);
+            for (int64_t ib = ilo + g; ib < j0; ib += 32) { // four loads in flight per lane
+                double av[4];
 #pragma unroll
-                    for (int k = 0; k < GB_CB; ++k) acc[k] += a * L.w[rho * GB_CB + k];
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t i = ib + 8 * q;
+                    av[q] = (i < j0) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t i = ib + 8 * q;
+                    if (i < j0) {
+                        const int rho = static_cast<int>(i - i0);
+#pragma unroll
+                        for (int k = 0; k < GB_CB; ++k) acc[k] += av[q] * L.w[rho * GB_CB + k];
+                    }
                 }
             }
         }
@@ -531,11 +560,21 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
     }
     __syncthreads();
     if (tid < GB_CB) {
-        for (int c = 0; c < ncol; ++c) {
-            double x = L.w[(top + c) * GB_CB + tid] - L.part[c * GB_CB + tid];
-            for (int cc = 0; cc < c; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * L.w[(top + cc) * GB_CB + tid];
-            L.w[(top + c) * GB_CB + tid] = x / L.blk[c * (GB_NB + 1) + c];
+        double xs[GB_NB];
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) {
+            if (c < ncol) {
+                double x = xs[c];
+#pragma unroll
+                for (int cc = 0; cc < c; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * xs[cc];
+                xs[c] = x / L.blk[c * (GB_NB + 1) + c];
+            }
         }
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c)
+            if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
     }
     __syncthreads();
     for (int k = 0; k < GB_CB; ++k)
@@ -562,11 +601,20 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
         for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
         if (c < ncol) {
             const int hi = (c + kl < R - 1) ? c + kl : R - 1;
-            for (int rho = ncol + g; rho <= hi; rho += 8) {
-                const double a = ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab];
-                if (a != 0.0) {
+            for (int rb = ncol + g; rb <= hi; rb += 32) {
+                double av[4];
 #pragma unroll
-                    for (int k = 0; k < GB_CB; ++k) acc[k] += a * L.w[rho * GB_CB + k];
+                for (int q = 0; q < 4; ++q) {
+                    const int rho = rb + 8 * q;
+                    av[q] = (rho <= hi) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rho = rb + 8 * q;
+                    if (rho <= hi) {
+#pragma unroll
+                        for (int k = 0; k < GB_CB; ++k) acc[k] += av[q] * L.w[rho * GB_CB + k];
+                    }
                 }
             }
         }
@@ -583,11 +631,19 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
     __syncthreads();
     if (tid < GB_CB) {
         const int lim = (ncol < R) ? ncol : R;
-        for (int c = lim - 1; c >= 0; --c) {
-            double x = L.w[c * GB_CB + tid] - L.part[c * GB_CB + tid];
-            for (int cc = c + 1; cc < lim; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * L.w[cc * GB_CB + tid];
-            L.w[c * GB_CB + tid] = x;
+        double xs[GB_NB];
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
+#pragma unroll
+        for (int c = GB_NB - 2; c >= 0; --c) {
+            double x = xs[c];
+#pragma unroll
+            for (int cc = c + 1; cc < GB_NB; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * xs[cc]; // (blk is zero outside the panel)
+            xs[c] = x;
         }
+#pragma unroll
+        for (int c = 0; c < GB_NB; ++c)
+            if (c < lim) L.w[c * GB_CB + tid] = xs[c];
     }
     __syncthreads();
     const int lim = (ncol < R) ? ncol : R;
@@ -725,16 +781,7 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
     const int rows = kl + GB_NB; // rows of a panel: a row per lane and register slot
     for (int64_t j0 = 0; j0 < n; j0 += GB_NB) {
         const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
-        if (rows <= 64) // narrow bands: ONE wave, up to three rows per lane -- the barriers of a step cost nothing
-            hipLaunchKernelGGL((k_gb_panel<64, 1>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
-                               h->replaced);
-        else if (rows <= 128)
-            hipLaunchKernelGGL((k_gb_panel<64, 2>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
-                               h->replaced);
-        else if (rows <= 192)
-            hipLaunchKernelGGL((k_gb_panel<64, 3>), dim3(1), dim3(64), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
-                               h->replaced);
-        else if (rows <= 256)
+        if (rows <= 256) // (one wave with three rows per lane measured slower: 88 us per panel against 74 us)
             hipLaunchKernelGGL((k_gb_panel<256, 1>), dim3(1), dim3(256), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
                                h->replaced);
         else if (rows <= 512)

@@ -82,6 +82,8 @@ struct sx_rowblock {
 // when at least half of them land in windowed cells; 0 never; 1 whenever the matrix admits it).  *out is
 // nullptr when the plain walk should be used.  Built on first use and kept by the matrix.
 constexpr int64_t RB_AUTO_NNZ = 1 << 22;
+constexpr int64_t RB_AUTO_ROWS = 1 << 18; // ... and of at least 512 super-tiles of 512 rows: below, the walk has too few
+                                          // workgroups to fill the chip (1e5 rows x 8e6 entries: 175 us against 110 us plain)
 int sx_rowblock_get(sx_ctx *ctx, const sx_matrix *A, const sx_rowblock **out);
 void sx_rowblock_free(sx_rowblock *rb);
 

@@ -421,7 +421,7 @@ int sx_rowblock_get(sx_ctx *ctx, const sx_matrix *A, const sx_rowblock **out) {
     const int opt = ctx->opt_rowblock;
     if (opt == 0 || A->csr_ptr == nullptr || A->csr_tiles == nullptr) return SX_OK;
     const bool force = opt > 0;
-    if (!force && A->nnz < RB_AUTO_NNZ) return SX_OK;
+    if (!force && (A->nnz < RB_AUTO_NNZ || A->m < RB_AUTO_ROWS)) return SX_OK;
     // the verdict of a forced build covers the automatic one, not the other way round
     if (!A->rb && A->rb_tried < (force ? 2 : 1)) {
         A->rb_tried = force ? 2 : 1;

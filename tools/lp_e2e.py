@@ -20,6 +20,9 @@ def main():
     which = sys.argv[1]
     kw = dict(a.split("=") for a in sys.argv[2:])
     from smart_crossover.formats import GeneralLP
+    if os.environ.get("SX_ROWBLOCK") is not None:
+        from smart_crossover.hip import default_context
+        default_context().set_option("rowblock", int(os.environ["SX_ROWBLOCK"]))
     from smart_crossover.lp_methods import algorithms as alg
     from smart_crossover.solver_caller.caller import SolverSettings
     from smart_crossover.solver_caller import solving
