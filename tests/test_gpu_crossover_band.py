@@ -121,3 +121,66 @@ def test_headline_size_1e6_variables(ctx, monkeypatch):
     certificates(mgr.lp_sub, out)
     with redirect_stdout(io.StringIO()):
         assert alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x)) is True
+
+
+def small_band_lp(m=400, n=1600, seed=11):
+    """A well-conditioned staircase LP in computational form for direct calls of the sparse crossover."""
+    inst = workloads.netlib_lp(m, n, seed=seed)
+    return inst
+
+
+def direct(ctx, A, b, c, l, u, lt, x_start):
+    m, n = A.shape
+    dA = ctx.matrix(A)
+    put = lambda v, t=np.float64: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+    d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
+    res = ctx.crossover_band(dA, put(b), put(c), put(l), put(u), put(lt, np.uint8), put(x_start), 0, 1e-7, 1e-7, d_x, d_y, d_vb, d_cb)
+    out = (res, d_x.download(), d_y.download(), d_vb.download().astype(int), d_cb.download().astype(int))
+    dA.free()
+    return out
+
+
+def test_direct_call_from_a_poor_start_reaches_highs_optimum(ctx):
+    """No first-order stage in front: the interior point of the ORIGINAL problem as the start of the crossover of the
+    whole LP (all 1,600 columns; most of them non-basic at a bound) -- phase 1, superbasic pushes and column
+    generation all have to work.  Optimum = HiGHS', certificates hold."""
+    inst = small_band_lp()
+    lt = inst.sense == "<"
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, inst.x)
+    assert int(res.status) == 0
+    ref = linprog(inst.c, A_ub=inst.A[lt], b_ub=inst.b[lt], A_eq=inst.A[~lt], b_eq=inst.b[~lt],
+                  bounds=list(zip(inst.l, [None if np.isinf(v) else v for v in inst.u])), method="highs")
+    assert ref.status == 0
+    assert float(inst.c @ x) == pytest.approx(ref.fun, rel=1e-8, abs=1e-8)
+    m = inst.A.shape[0]
+    s_p = inst.b - inst.A @ x
+    assert np.abs(s_p[~lt]).max() < 1e-6 and s_p[lt].min() > -1e-6
+    assert np.all(x >= inst.l - 1e-9) and np.all(x <= inst.u + 1e-9)
+    rc = inst.c - inst.A.T @ y
+    assert np.all(rc[vb == -1] >= -1e-6) and np.all(rc[vb == -2] <= 1e-6) and np.abs(rc[vb == 0]).max() < 1e-6
+    assert int((vb == 0).sum() + (cb == 0).sum()) == m
+
+
+def test_infeasible_and_unbounded_are_reported(ctx):
+    inst = small_band_lp(seed=12)
+    lt = inst.sense == "<"
+    # infeasible: one '=' row asks for more than its columns' bounds can give
+    b = inst.b.copy()
+    i = int(np.flatnonzero(~lt)[5])
+    u = np.where(np.isinf(inst.u), 50.0, inst.u)
+    b[i] = 1e6
+    res = direct(ctx, inst.A, b, inst.c, inst.l, u, lt, np.clip(inst.x, inst.l, u))[0]
+    assert int(res.status) == 1
+    # unbounded: a column without an upper bound that touches only '<' rows with negative entries and pays to grow
+    A = inst.A.tolil()
+    j = int(np.flatnonzero(np.isinf(inst.u))[3])
+    rows_lt = np.flatnonzero(lt)[:3]
+    A[:, j] = 0
+    for r in rows_lt:
+        A[r, j] = -1.0
+    A = A.tocsr()
+    c = inst.c.copy()
+    c[j] = -1.0
+    res = direct(ctx, A, inst.A @ inst.x + np.where(lt, 0.5, 0.0), c, inst.l, inst.u, lt, inst.x)[0]
+    assert int(res.status) == 2
