@@ -67,6 +67,9 @@ int sx_ctx_sync(sx_ctx *ctx);
  * with nt / sc1 / sc0 sc1 / nt sc1), "chunk" 2048/4096 (default 4096), "window" (LDS operand window of the
  * column walk in K1/K10: -1 auto [default: decided per matrix from its index clustering on first use],
  * 0 off, 1/2/4/8 tiles per window load), "graph" 0/1 (default 1: hipGraph replay of the CG iteration batch),
+ * "rb_stage_long" (0/1, default 0: in the column-blocked row layout the products of the long rows come from a
+ * column-ordered pre-pass instead of one gathered 128-byte line per entry -- bit-identical, measured slower, kept
+ * as an experiment; read when a layout is built),
  * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
  * of a batch of 64 pivots are kept in product form and folded in as one rank-64 update -- by rocblas_dgemm on the
  * fp64 matrix cores from 8192 rows on --, -1 auto [default]),

@@ -41,7 +41,7 @@ struct sx_rb_chunk {
     int32_t cell;  // cell number (-> rowstart)
     int32_t base;  // offset of the chunk's first entry inside its cell
     int32_t fresh; // 1: first chunk of its cell (new rowstart, new window)
-    int32_t pad_;
+    int32_t staged; // 1: chunk of a long-row super-tile whose products a pre-pass leaves in lprod (below)
 };
 
 struct sx_rb_supertile {
@@ -76,6 +76,14 @@ struct sx_rowblock {
     uint16_t *rowstart = nullptr;
     int32_t *idx = nullptr;
     double *val = nullptr;
+    // Long rows (the linking rows of an LP) gather x one 128-byte line per entry -- 1.28 GB of the 2.26 GB K2 moved at
+    // config 5.  Their entries are therefore ALSO kept sorted by column (lcol / lval, and le = the entry's slot in
+    // idx / val): a pre-pass streams that list and x in column order, forms the same rounded products and scatters
+    // them to lprod[le]; the walk then reads the products of a staged chunk instead of entries + gathers.  Same
+    // products, same order of the adds: bit-identical sums.
+    int64_t nl = 0;
+    int32_t *lcol = nullptr, *le = nullptr;
+    double *lval = nullptr, *lprod = nullptr;
 };
 
 // Layout of A's rows under ctx's "rowblock" option (-1 auto: built for matrices of >= RB_AUTO_NNZ entries

@@ -38,8 +38,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rb_rsrc(const void *p, uint32_
 }
 
 __device__ __forceinline__ void rb_load(RbEntries &E, const sx_rb_chunk &c, const int32_t *__restrict__ idx,
-                                        const double *__restrict__ val) {
+                                        const double *__restrict__ val, const double *__restrict__ lprod) {
     const uint32_t ne4 = static_cast<uint32_t>((c.ne + 3) & ~3);
+    if (c.staged && lprod) { // the chunk's products are there already: 8 bytes per entry, no gather
+        const __amdgpu_buffer_rsrc_t rp = rb_rsrc(lprod + c.e0, ne4 * 8u);
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < RB_NQ; ++q) {
+            E.v01[q] = __builtin_bit_cast(sx_v2d, __builtin_amdgcn_raw_buffer_load_b128(rp, tid * 32, q * RB_TW * 32, RB_NT));
+            E.v23[q] = __builtin_bit_cast(sx_v2d, __builtin_amdgcn_raw_buffer_load_b128(rp, tid * 32 + 16, q * RB_TW * 32, RB_NT));
+        }
+        return;
+    }
     const __amdgpu_buffer_rsrc_t ri = rb_rsrc(idx + c.e0, ne4 * 4u), rv = rb_rsrc(val + c.e0, ne4 * 8u);
     const int tid = threadIdx.x;
 #pragma unroll
@@ -52,9 +62,17 @@ __device__ __forceinline__ void rb_load(RbEntries &E, const sx_rb_chunk &c, cons
 
 // lanes past the chunk hold zeros (index 0, value 0.0): their products land in slots no row segment covers
 __device__ __forceinline__ void rb_stage(const RbEntries &E, const sx_rb_chunk &c, const double *win,
-                                         const double *__restrict__ x, double *prod) {
+                                         const double *__restrict__ x, double *prod, bool staged) {
     const int tid = threadIdx.x;
-    if (c.col0 != RB_NO_WINDOW) {
+    if (staged) {
+#pragma unroll
+        for (int q = 0; q < RB_NQ; ++q) {
+            const int off = q * RB_TW * 4 + tid * 4;
+            double2 *dst = reinterpret_cast<double2 *>(prod + off);
+            dst[0] = make_double2(E.v01[q].x, E.v01[q].y);
+            dst[1] = make_double2(E.v23[q].x, E.v23[q].y);
+        }
+    } else if (c.col0 != RB_NO_WINDOW) {
         const double *w0 = win - c.col0; // only dereferenced inside [win, win + RB_CWIN)
 #pragma unroll
         for (int q = 0; q < RB_NQ; ++q) {
@@ -139,7 +157,7 @@ __device__ __forceinline__ sx_rb_chunk rb_record(const int *tab, int slot) {
     c.cell = __builtin_amdgcn_readfirstlane(p[4]);
     c.base = __builtin_amdgcn_readfirstlane(p[5]);
     c.fresh = __builtin_amdgcn_readfirstlane(p[6]);
-    c.pad_ = 0;
+    c.staged = __builtin_amdgcn_readfirstlane(p[7]);
     return c;
 }
 
@@ -150,6 +168,7 @@ struct RbLayout {
     const int32_t *__restrict__ idx;
     const double *__restrict__ val;
     int64_t nst;
+    const double *__restrict__ lprod; // products of the staged (long-row) chunks, or nullptr
 };
 
 // acc[r] = sum of row S.row0 + tid + r * RB_TW over the super-tile (0 for rows beyond its end); all lanes of the
@@ -200,7 +219,7 @@ __device__ __forceinline__ void rb_supertile_sum(const RbLayout &L, const sx_rb_
     sx_rb_chunk c = rb_record(lds.tab, 0);
     load_rs(rs, c);
     if (c.col0 != RB_NO_WINDOW) load_win(wreg, c);
-    rb_load(E[0], c, L.idx, L.val);
+    rb_load(E[0], c, L.idx, L.val, L.lprod);
     if (c.col0 != RB_NO_WINDOW) store_win(wreg);
     __syncthreads();
     auto step = [&](RbEntries &Ecur, RbEntries &Enext, int k) {
@@ -210,8 +229,8 @@ __device__ __forceinline__ void rb_supertile_sum(const RbLayout &L, const sx_rb_
         const bool new_win = open && cn.col0 != RB_NO_WINDOW;
         if (open) load_rs(rs_next, cn);
         if (new_win) load_win(wreg, cn);
-        if (has_next) rb_load(Enext, cn, L.idx, L.val);
-        rb_stage(Ecur, c, lds.win, x, lds.prod);
+        if (has_next) rb_load(Enext, cn, L.idx, L.val, L.lprod);
+        rb_stage(Ecur, c, lds.win, x, lds.prod, c.staged && L.lprod);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < RB_RPL; ++r) rb_consume(acc[r], rs[r][0], rs[r][1], c.base, c.ne, lds.prod);
@@ -324,7 +343,16 @@ __global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swiz
 }
 
 inline RbLayout layout_of(const sx_rowblock *rb) {
-    return RbLayout{rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->nst};
+    return RbLayout{rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->nst, rb->nl > 0 ? rb->lprod : nullptr};
+}
+
+// pre-pass of the long rows: products in column order (x streamed), scattered to their slots
+__global__ __launch_bounds__(SX_WG) void k_rb_long_products(int64_t nl, const int32_t *__restrict__ lcol, const double *__restrict__ lval,
+                                                            const int32_t *__restrict__ le, const double *__restrict__ x,
+                                                            double *__restrict__ lprod, const RbCgState *st) {
+    if (st && st->done) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    if (i < nl) lprod[le[i]] = lval[i] * x[lcol[i]];
 }
 
 } // namespace
@@ -334,6 +362,9 @@ int sx_rb_score_rows(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const do
     if (rb->nst == 0) return SX_OK;
     const int swz = ctx->opt_xcd_swizzle;
     const unsigned grid = swz ? static_cast<unsigned>(((rb->nst + 7) >> 3) << 3) : static_cast<unsigned>(rb->nst);
+    if (rb->nl > 0)
+        hipLaunchKernelGGL(k_rb_long_products, dim3(static_cast<unsigned>((rb->nl + SX_WG - 1) / SX_WG)), dim3(SX_WG), 0, ctx->stream,
+                           rb->nl, rb->lcol, rb->lval, rb->le, x, rb->lprod, static_cast<const RbCgState *>(nullptr));
     hipLaunchKernelGGL(k_rb_score_rows, dim3(grid), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, x, ncols, b, y,
                        gamma_dual, s_p, flag);
     SX_HIP(hipGetLastError());
@@ -346,6 +377,9 @@ int sx_rb_cg_a(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const void *cg
     const int swz = (ctx->opt_xcd_swizzle && rb->nst >= 64) ? 1 : 0;
     if (swz) g &= ~static_cast<int64_t>(7);
     if (g < 1) g = 1;
+    if (rb->nl > 0)
+        hipLaunchKernelGGL(k_rb_long_products, dim3(static_cast<unsigned>((rb->nl + SX_WG - 1) / SX_WG)), dim3(SX_WG), 0, ctx->stream,
+                           rb->nl, rb->lcol, rb->lval, rb->le, w, rb->lprod, static_cast<const RbCgState *>(cg_state));
     hipLaunchKernelGGL(k_rb_cg_a, dim3(static_cast<unsigned>(g)), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz,
                        static_cast<const RbCgState *>(cg_state), w, ncols, xs, p, q, partial);
     SX_HIP(hipGetLastError());

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SX_WG) void k_rb_chunks(int64_t ncells, const int64
         c.cell = static_cast<int32_t>(cell);
         c.base = static_cast<int32_t>(base);
         c.fresh = base == 0 ? 1 : 0;
-        c.pad_ = 0;
+        c.staged = 0;
         chunks[k] = c;
     }
 }
@@ -221,6 +221,46 @@ __global__ __launch_bounds__(SX_WG) void k_rb_supertiles(int64_t nst, const int6
     r.chunk0 = ch_first[cell_base[s]];
     r.nchunks = static_cast<int32_t>(ch_first[cell_base[s + 1]] - r.chunk0);
     st[s] = r;
+}
+
+// ---- long rows: mark their chunks, list their entries (column, slot), later sorted by column
+__global__ __launch_bounds__(SX_WG) void k_rb_mark_long(int64_t nst, const sx_rb_supertile *__restrict__ st,
+                                                        const int32_t *__restrict__ slice, sx_rb_chunk *__restrict__ chunks,
+                                                        unsigned long long *__restrict__ count) {
+    const int64_t s = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    if (s >= nst || slice[s] == 0) return;
+    unsigned long long tot = 0;
+    for (int64_t k = st[s].chunk0; k < st[s].chunk0 + st[s].nchunks; ++k) {
+        chunks[k].staged = 1;
+        tot += static_cast<unsigned long long>(chunks[k].ne);
+    }
+    atomicAdd(count, tot);
+}
+// one workgroup per chunk; the order of the list does not matter (it is sorted by column afterwards, and equal
+// columns scatter to different slots)
+__global__ __launch_bounds__(SX_WG) void k_rb_long_fill(int64_t nchunks, const sx_rb_chunk *__restrict__ chunks,
+                                                        const int32_t *__restrict__ idx, unsigned long long *__restrict__ cursor,
+                                                        uint64_t *__restrict__ key, int32_t *__restrict__ pay) {
+    __shared__ unsigned long long base;
+    const int64_t k = blockIdx.x;
+    if (k >= nchunks) return;
+    const sx_rb_chunk c = chunks[k];
+    if (!c.staged) return;
+    if (threadIdx.x == 0) base = atomicAdd(cursor, static_cast<unsigned long long>(c.ne));
+    __syncthreads();
+    for (int t = threadIdx.x; t < c.ne; t += SX_WG) {
+        key[base + t] = static_cast<uint64_t>(static_cast<uint32_t>(idx[c.e0 + t]));
+        pay[base + t] = static_cast<int32_t>(c.e0 + t);
+    }
+}
+__global__ __launch_bounds__(SX_WG) void k_rb_long_lists(int64_t nl, const uint64_t *__restrict__ key, const int32_t *__restrict__ pay,
+                                                         const double *__restrict__ val, int32_t *__restrict__ lcol,
+                                                         int32_t *__restrict__ le, double *__restrict__ lval) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    if (i >= nl) return;
+    lcol[i] = static_cast<int32_t>(key[i]);
+    le[i] = pay[i];
+    lval[i] = val[pay[i]];
 }
 
 // temporaries of one build: freed on every exit path
@@ -400,6 +440,45 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
                        d_ch_first, rb->chunks);
     hipLaunchKernelGGL(k_rb_supertiles, dim3(grid1d(nst)), dim3(SX_WG), 0, s, nst, d_cuts, d_cell_base, d_ch_first, rb->st);
     SX_HIP(hipGetLastError());
+    // ---- long rows: their entries once more, sorted by column, for the product pre-pass (sx_rowblock.h)
+    if (ctx->opt_rb_stage_long) {
+        unsigned long long *d_cnt2;
+        SX_TRY(tmp.get(2, &d_cnt2, true, s));
+        hipLaunchKernelGGL(k_rb_mark_long, dim3(grid1d(nst)), dim3(SX_WG), 0, s, nst, rb->st, d_slice, rb->chunks, d_cnt2);
+        unsigned long long nl = 0;
+        SX_HIP(hipMemcpyAsync(&nl, d_cnt2, sizeof(nl), hipMemcpyDeviceToHost, s));
+        SX_HIP(hipStreamSynchronize(s));
+        if (nl > 0 && nl < INT32_MAX && nent + 8 < INT32_MAX) {
+            uint64_t *lkey[2];
+            int32_t *lpay[2];
+            int64_t *lhist, *loffs;
+            const int64_t lblocks = sx_sort_blocks(static_cast<int64_t>(nl));
+            for (int k = 0; k < 2; ++k) {
+                SX_TRY(tmp.get(static_cast<size_t>(nl), &lkey[k], false, s));
+                SX_TRY(tmp.get(static_cast<size_t>(nl), &lpay[k], false, s));
+            }
+            SX_TRY(tmp.get(static_cast<size_t>(256 * lblocks + 1), &lhist, false, s));
+            SX_TRY(tmp.get(static_cast<size_t>(256 * lblocks + 1), &loffs, false, s));
+            hipLaunchKernelGGL(k_rb_long_fill, dim3(static_cast<unsigned>(nchunks)), dim3(SX_WG), 0, s, nchunks, rb->chunks, rb->idx,
+                               d_cnt2 + 1, lkey[0], lpay[0]);
+            int cbits = 1;
+            while ((static_cast<int64_t>(1) << cbits) < n) ++cbits;
+            int lcur = 0;
+            SX_TRY(sx_sort_pairs(ctx, static_cast<int64_t>(nl), lkey, lpay, lhist, loffs, (cbits + 7) / 8, &lcur));
+            rb->nl = static_cast<int64_t>(nl);
+            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lcol), sizeof(int32_t) * static_cast<size_t>(nl)));
+            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->le), sizeof(int32_t) * static_cast<size_t>(nl)));
+            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lval), sizeof(double) * static_cast<size_t>(nl)));
+            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lprod), sizeof(double) * static_cast<size_t>(nent + 8)));
+            SX_HIP(hipMemsetAsync(rb->lprod, 0, sizeof(double) * static_cast<size_t>(nent + 8), s));
+            hipLaunchKernelGGL(k_rb_long_lists, dim3(grid1d(static_cast<int64_t>(nl))), dim3(SX_WG), 0, s, static_cast<int64_t>(nl),
+                               lkey[lcur], lpay[lcur], rb->val, rb->lcol, rb->le, rb->lval);
+            SX_HIP(hipGetLastError());
+        } else if (nl > 0) { // too large for 32-bit slots: the chunks go back to the gather
+            SX_HIP(hipMemsetAsync(d_cnt2, 0, 2 * sizeof(unsigned long long), s));
+            rb->nl = -1;
+        }
+    }
     SX_HIP(hipStreamSynchronize(s)); // the temporaries go away when this function returns
     guard.rb = nullptr;
     *out = rb;
@@ -410,7 +489,7 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
 
 void sx_rowblock_free(sx_rowblock *rb) {
     if (!rb) return;
-    void *ptrs[5] = {rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val};
+    void *ptrs[9] = {rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->lcol, rb->le, rb->lval, rb->lprod};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete rb;
