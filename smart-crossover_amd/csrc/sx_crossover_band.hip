@@ -709,6 +709,79 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     }
     const int64_t m1 = static_cast<int64_t>(rows_band.size()), ndr = static_cast<int64_t>(rows_dense.size());
     std::vector<int32_t> rowb(static_cast<size_t>(m), -1);
+    // ---- the order of the band rows.  Natural order first (staged models are written stage after stage); when
+    // that leaves some column taller than a band can be, a Cuthill-McKee order of the rows (breadth first over
+    // "shares a column with", from a far end found by one extra sweep) -- rows of a model that was shuffled, or
+    // written variable by variable, fall back into stages.
+    {
+        auto tallest = [&](const std::vector<int32_t> &order) {
+            std::vector<int32_t> where(static_cast<size_t>(m), -1);
+            for (size_t k = 0; k < order.size(); ++k) where[order[k]] = static_cast<int32_t>(k);
+            int32_t worst = 0;
+            for (int64_t j = 0; j < n; ++j) {
+                int32_t lo = INT32_MAX, hi = -1;
+                for (int64_t k = cptr[j]; k < cptr[j + 1]; ++k) {
+                    const int32_t ib = where[cidx[k]];
+                    if (ib >= 0) {
+                        lo = std::min(lo, ib);
+                        hi = std::max(hi, ib);
+                    }
+                }
+                if (hi >= 0) worst = std::max(worst, hi - lo);
+            }
+            return worst;
+        };
+        const int32_t tall_nat = tallest(rows_band);
+        if (tall_nat > 600 && m1 > 1) {
+            std::vector<int32_t> ridx;
+            SX_TRY(down(s, ridx, A->csr_idx, static_cast<size_t>(A->nnz)));
+            SX_HIP(hipStreamSynchronize(s));
+            std::vector<uint8_t> is_band(static_cast<size_t>(m), 0);
+            for (int32_t r : rows_band) is_band[r] = 1;
+            const int64_t col_cap = std::max<int64_t>(64, static_cast<int64_t>(16.0 * static_cast<double>(A->nnz) / static_cast<double>(n)));
+            auto sweep = [&](int32_t start, std::vector<int32_t> &order) { // breadth first over all components, `start` first
+                order.clear();
+                std::vector<uint8_t> seen(static_cast<size_t>(m), 0), used(static_cast<size_t>(n), 0);
+                size_t next_seed = 0;
+                int32_t seed = start;
+                while (static_cast<int64_t>(order.size()) < m1) {
+                    if (seed < 0) {
+                        while (next_seed < rows_band.size() && seen[rows_band[next_seed]]) ++next_seed;
+                        if (next_seed >= rows_band.size()) break;
+                        seed = rows_band[next_seed];
+                    }
+                    size_t head_q = order.size();
+                    seen[seed] = 1;
+                    order.push_back(seed);
+                    for (; head_q < order.size(); ++head_q) {
+                        const int32_t i = order[head_q];
+                        for (int64_t k = rptr[i]; k < rptr[i + 1]; ++k) {
+                            const int32_t j = ridx[k];
+                            if (used[j]) continue;
+                            used[j] = 1;
+                            if (cptr[j + 1] - cptr[j] > col_cap) continue; // a column that touches everything orders nothing
+                            for (int64_t q = cptr[j]; q < cptr[j + 1]; ++q) {
+                                const int32_t i2 = cidx[q];
+                                if (is_band[i2] && !seen[i2]) {
+                                    seen[i2] = 1;
+                                    order.push_back(i2);
+                                }
+                            }
+                        }
+                    }
+                    seed = -1;
+                }
+            };
+            std::vector<int32_t> o1, o2;
+            sweep(rows_band[0], o1);
+            sweep(o1.empty() ? rows_band[0] : o1.back(), o2); // from the far end of the first sweep
+            if (static_cast<int64_t>(o2.size()) == m1) {
+                const int32_t tall_cm = tallest(o2);
+                if (trace) fprintf(stderr, "[sx_crossover_band] tallest column: %d rows in natural order, %d in Cuthill-McKee order\n", tall_nat, tall_cm);
+                if (tall_cm < tall_nat) rows_band = o2;
+            }
+        }
+    }
     for (int64_t k = 0; k < m1; ++k) {
         rowb[rows_band[k]] = static_cast<int32_t>(k);
         eqidx[rows_band[k]] = static_cast<int32_t>(k);

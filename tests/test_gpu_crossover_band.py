@@ -184,3 +184,27 @@ def test_infeasible_and_unbounded_are_reported(ctx):
     c[j] = -1.0
     res = direct(ctx, A, inst.A @ inst.x + np.where(lt, 0.5, 0.0), c, inst.l, inst.u, lt, inst.x)[0]
     assert int(res.status) == 2
+
+
+def test_shuffled_rows_fall_back_into_a_band(ctx, monkeypatch):
+    """The same staircase LP with its rows (and columns) shuffled: no band in the natural order; the Cuthill-McKee
+    order of the rows finds it again and the sparse crossover reaches the vertex of the un-shuffled problem."""
+    from smart_crossover.lp_methods import algorithms as alg
+    inst = workloads.netlib_lp(4000, 40000, seed=8)
+    rng = np.random.default_rng(1)
+    pr, pc = rng.permutation(inst.A.shape[0]), rng.permutation(inst.A.shape[1])
+    shuf = workloads.LPInstance(A=inst.A[pr][:, pc].tocsr(), b=inst.b[pr], c=inst.c[pc], l=inst.l[pc], u=inst.u[pc],
+                                sense=inst.sense[pr], x=inst.x[pc], y=inst.y[pr])
+    shuf.A.sort_indices()
+    lp0, mgr0 = perturbed_sub_problem(inst)
+    lp1, mgr1 = perturbed_sub_problem(shuf)
+    c0, o0 = resolve(mgr0, inst, monkeypatch, "band")
+    c1, o1 = resolve(mgr1, shuf, monkeypatch, "band")
+    assert c0.solved_by == c1.solved_by == "crossover_band"
+    assert o0.status == o1.status == "OPTIMAL"
+    certificates(mgr1.lp_sub, o1)
+    with redirect_stdout(io.StringIO()):
+        assert alg.check_perturb_output_precision(mgr1, o1.x, lp1.c, float(lp1.c @ shuf.x)) is True
+    # same LP up to the permutation (the perturbation xi is drawn per position, so only the original objectives agree)
+    x0, x1 = mgr0.get_orix(o0.x), mgr1.get_orix(o1.x)
+    assert float(inst.c @ x0) == pytest.approx(float(shuf.c @ x1), rel=1e-7)
