@@ -40,10 +40,38 @@ struct TbState {
     int hit;     // bound the leaving variable stops at: 1 lower, 2 upper
     int n_inf;
     int n_bl;       // blocks of 256 positions in which the entering column has an entry (their list: blist)
-    int b_pad;
-    int pad;
+    int n_pend;     // basis changes whose rank-one updates are not applied to T yet (product form: TbPend)
+    int folding;    // the batch's fold is under way
     double theta, alpha_r, dq, sum_inf, feas_tol, opt_tol, tmax;
 };
+
+// Pending updates of a batch (product form).  Pivot s of the batch has entering slot q_s, leaving position r_s,
+// u_s = alpha_s - e_{r_s} (alpha_s is the eta vector of the pivot) and v_s = row r_s of the tableau at that time
+// divided by the pivot element (v_s[q_s] = 1 / pivot).  The current tableau column of slot j is
+//     base_j - sum_{s >= s0[j]} u_s v_s[j],   base_j = T[:, j]  or  e_{sbase[j]} once j has been an entering slot,
+// and row r is the same expression read across -- k vectors of m resp. |J| entries per pivot instead of a pass over
+// the whole m x |J| tableau; k_tb_fold applies a batch in ONE pass (at 1e6 rows x 8,600 columns a rank-one update
+// is 130 GB of traffic, 16 ms; the batch of 48-64 costs the same once).
+constexpr int TB_K = 64;
+struct TbPend {
+    const double *vbuf; // [TB_K][ldv]
+    const int32_t *pr;  // [TB_K] leaving position of the pending pivots
+    const int32_t *s0;  // [slots] first pending pivot that applies to the slot
+    const int32_t *sbase; // [slots] -1: base column is T's; >= 0: base column is that unit vector
+    int64_t ldv;
+};
+__device__ __forceinline__ double tb_current(const double *__restrict__ T, const double *__restrict__ eta, const TbState *st,
+                                              const TbPend &P, int64_t m, int64_t p, int j) {
+    const int sb = P.sbase[j];
+    double a = sb < 0 ? T[static_cast<size_t>(j) * m + p] : (p == sb ? 1.0 : 0.0);
+    const int np = st->n_pend;
+    const long long e0 = st->n_eta - np;
+    for (int s = P.s0[j]; s < np; ++s) {
+        const double u = eta[static_cast<size_t>(e0 + s) * m + p] - (p == P.pr[s] ? 1.0 : 0.0);
+        a -= u * P.vbuf[static_cast<size_t>(s) * P.ldv + j];
+    }
+    return a;
+}
 
 struct TbPart {
     double t, a;
@@ -155,16 +183,18 @@ __global__ __launch_bounds__(TB_WG) void k_tb_phase(int nblk, const double *__re
     }
 }
 
-// phase 1 only: d1[s] = - sum_p g[p] T[p, s].  Few basic variables are infeasible behind a first-order point, so
-// a workgroup (one per tracked column) visits only the blocks of 256 positions that hold one (counts from
-// k_tb_infeas), a lane per block; with many of them it reads the column whole, coalesced.
-__global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const double *__restrict__ T, const double *__restrict__ g,
-                                                     const double *__restrict__ part, const TbState *__restrict__ st,
-                                                     double *__restrict__ d1) {
+// phase 1 only: d1[j] = - g^T (current column j) = -( g^T base_j - sum_{s >= s0[j]} (g^T u_s) v_s[j] ).  Few basic
+// variables are infeasible behind a first-order point, so g^T T[:, j] visits only the blocks of 256 positions that
+// hold one (counts from k_tb_infeas), a lane per block; with many of them it reads the column whole, coalesced.
+__global__ __launch_bounds__(TB_WG) void k_tb_gu(int64_t m, int nblk, const double *__restrict__ eta, const double *__restrict__ g,
+                                                 const double *__restrict__ part, const TbState *__restrict__ st, TbPend P,
+                                                 double *__restrict__ gu) {
     __shared__ double sm[4];
     if (st->status != 0 || st->phase != 1) return;
-    const int64_t s = blockIdx.x;
-    const double *col = T + static_cast<size_t>(s) * m;
+    const int sidx = blockIdx.x;
+    if (sidx >= st->n_pend) return;
+    const double *al = eta + static_cast<size_t>(st->n_eta - st->n_pend + sidx) * m;
+    const int r = P.pr[sidx];
     double acc = 0.0;
     if (st->n_inf <= 4096) {
         for (int k = threadIdx.x; k < nblk; k += TB_WG)
@@ -172,17 +202,52 @@ __global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const 
                 const int64_t p0 = static_cast<int64_t>(k) * TB_WG, p1 = (p0 + TB_WG < m) ? p0 + TB_WG : m;
                 for (int64_t p = p0; p < p1; ++p) {
                     const double gp = g[p];
-                    if (gp != 0.0) acc += gp * col[p];
+                    if (gp != 0.0) acc += gp * (al[p] - (p == r ? 1.0 : 0.0));
                 }
             }
     } else {
         for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
             const double gp = g[p];
-            if (gp != 0.0) acc += gp * col[p];
+            if (gp != 0.0) acc += gp * (al[p] - (p == r ? 1.0 : 0.0));
         }
     }
     const double tot = tb_block_sum(acc, sm);
-    if (threadIdx.x == 0) d1[s] = -tot;
+    if (threadIdx.x == 0) gu[sidx] = tot;
+}
+
+__global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const double *__restrict__ T, const double *__restrict__ g,
+                                                     const double *__restrict__ part, const TbState *__restrict__ st, TbPend P,
+                                                     const double *__restrict__ gu, double *__restrict__ d1) {
+    __shared__ double sm[4];
+    if (st->status != 0 || st->phase != 1) return;
+    const int64_t s = blockIdx.x;
+    const int sb = P.sbase[s];
+    double acc = 0.0;
+    if (sb >= 0) {
+        if (threadIdx.x == 0) acc = g[sb];
+    } else {
+        const double *col = T + static_cast<size_t>(s) * m;
+        if (st->n_inf <= 4096) {
+            for (int k = threadIdx.x; k < nblk; k += TB_WG)
+                if (part[2 * k] > 0.0) {
+                    const int64_t p0 = static_cast<int64_t>(k) * TB_WG, p1 = (p0 + TB_WG < m) ? p0 + TB_WG : m;
+                    for (int64_t p = p0; p < p1; ++p) {
+                        const double gp = g[p];
+                        if (gp != 0.0) acc += gp * col[p];
+                    }
+                }
+        } else {
+            for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
+                const double gp = g[p];
+                if (gp != 0.0) acc += gp * col[p];
+            }
+        }
+    }
+    double tot = tb_block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        for (int k = P.s0[s]; k < st->n_pend; ++k) tot -= gu[k] * P.vbuf[static_cast<size_t>(k) * P.ldv + s];
+        d1[s] = -tot;
+    }
 }
 
 // entering column: superbasic columns first (they have to leave their interior value), then the largest
@@ -296,7 +361,7 @@ __device__ __forceinline__ void tb_row_limit(double a, double dir, double x, dou
 __global__ __launch_bounds__(TB_WG) void k_tb_ratio1(int64_t m, const double *__restrict__ T, const double *__restrict__ xB,
                                                      const double *__restrict__ lB, const double *__restrict__ uB,
                                                      const TbState *__restrict__ st, double *__restrict__ eta,
-                                                     double *__restrict__ part) {
+                                                     double *__restrict__ part, TbPend P) {
     __shared__ double sm[TB_WG];
     __shared__ int any_nz;
     if (st->status != 0) return;
@@ -306,7 +371,8 @@ __global__ __launch_bounds__(TB_WG) void k_tb_ratio1(int64_t m, const double *__
     const double dir = static_cast<double>(st->dir), tol = st->feas_tol;
     double t = INFINITY;
     if (p < m) {
-        const double a = T[static_cast<size_t>(st->q) * m + p];
+        double a = tb_current(T, eta, st, P, m, p, st->q);
+        if (fabs(a) < TB_DROP) a = 0.0;
         eta[static_cast<size_t>(st->n_eta) * m + p] = a;
         if (a != 0.0) any_nz = 1; // (benign race: every writer stores 1)
         if (fabs(a) > TB_PIV) {
@@ -471,51 +537,93 @@ __global__ __launch_bounds__(TB_WG) void k_tb_decide(int nblk, const TbPart *__r
     }
 }
 
-// row r of the tableau (before the update) -> rowbuf; alpha_r
-__global__ __launch_bounds__(TB_WG) void k_tb_rowcopy(int64_t m, int64_t nJ, const double *__restrict__ T, TbState *st,
-                                                      double *__restrict__ rowbuf) {
+// row r of the current tableau -> rowbuf; alpha_r
+__global__ __launch_bounds__(TB_WG) void k_tb_rowcopy(int64_t m, int64_t nJ, const double *__restrict__ T, const double *__restrict__ eta,
+                                                      TbState *st, TbPend P, double *__restrict__ rowbuf) {
     if (st->status != 0 || st->r < 0) return;
     const int64_t s = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
     if (s >= nJ) return;
-    const double v = T[static_cast<size_t>(s) * m + st->r];
+    double v = tb_current(T, eta, st, P, m, st->r, static_cast<int>(s));
+    if (fabs(v) < TB_DROP) v = 0.0;
+    if (s == st->q) {
+        v = eta[static_cast<size_t>(st->n_eta) * m + st->r]; // (the very number the ratio test saw)
+        st->alpha_r = v;
+    }
     rowbuf[s] = v;
-    if (s == st->q) st->alpha_r = v;
 }
 
-// x_B, and on a basis change the rank-one update of the tableau.  grid: (row workgroups, slot blocks of 32); the
-// row workgroups stride over the LIST of blocks of 256 positions in which the entering column has an entry at all --
-// B^-1 a_q of a band basis is local (plus the dense rows at the end), so at 1e6 rows a pivot touches a few thousand.
-__global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, int64_t nJ, double *__restrict__ T, double *__restrict__ xB,
-                                                     const double *__restrict__ eta, const double *__restrict__ rowbuf,
+// x_B moves along the entering column (only the blocks of positions in which that column has an entry); the
+// tableau itself is not touched: the pivot joins the pending batch (k_tb_post) and k_tb_fold applies the batch
+__global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, double *__restrict__ xB, const double *__restrict__ eta,
                                                      const TbState *__restrict__ st, const int32_t *__restrict__ blist) {
     if (st->status != 0) return;
-    const int r = st->r, q = st->q;
-    const double ar = st->alpha_r;
-    const int64_t s0 = static_cast<int64_t>(blockIdx.y) * 32, s1 = (s0 + 32 < nJ) ? s0 + 32 : nJ;
+    const int r = st->r;
     for (int e = blockIdx.x; e < st->n_bl; e += gridDim.x) {
         const int64_t p = static_cast<int64_t>(blist[e]) * TB_WG + threadIdx.x;
-        if (p >= m) continue;
+        if (p >= m || p == r) continue;
         const double a = eta[static_cast<size_t>(st->n_eta) * m + p];
-        if (blockIdx.y == 0 && p != r) xB[p] = xB[p] - static_cast<double>(st->dir) * st->theta * a;
-        if (r < 0) continue;
-        if (p == r) {
-            for (int64_t s = s0; s < s1; ++s) T[static_cast<size_t>(s) * m + p] = (s == q) ? 1.0 / ar : rowbuf[s] / ar;
-            continue;
+        if (a != 0.0) xB[p] = xB[p] - static_cast<double>(st->dir) * st->theta * a;
+    }
+}
+
+// One pass over the tableau for a whole batch: T[p, j] = base - sum_{s >= s0[j]} u_s[p] v_s[j].  A lane owns a
+// position (its u_s in registers, 64 at most), a workgroup 32 slots (their v_s in LDS).
+__global__ void k_tb_fold_begin(TbState *st, int slack) {
+    st->folding = (st->n_pend > 0 && (st->status != 0 || st->n_pend + slack > TB_K)) ? 1 : 0;
+}
+__global__ __launch_bounds__(TB_WG) void k_tb_fold(int64_t m, int64_t nJ, double *__restrict__ T, const double *__restrict__ eta,
+                                                   const TbState *__restrict__ st, TbPend P) {
+    __shared__ double vs[TB_K][33];
+    __shared__ int ss0[32], ssb[32];
+    if (!st->folding) return;
+    const int np = st->n_pend;
+    const long long e0 = st->n_eta - np;
+    const int64_t j0 = static_cast<int64_t>(blockIdx.y) * 32;
+    const int nj = static_cast<int>((nJ - j0 < 32) ? nJ - j0 : 32);
+    for (int e = threadIdx.x; e < TB_K * 32; e += TB_WG) {
+        const int sidx = e / 32, jj = e % 32;
+        vs[sidx][jj] = (sidx < np && jj < nj) ? P.vbuf[static_cast<size_t>(sidx) * P.ldv + j0 + jj] : 0.0;
+    }
+    if (threadIdx.x < 32) {
+        ss0[threadIdx.x] = threadIdx.x < nj ? P.s0[j0 + threadIdx.x] : np;
+        ssb[threadIdx.x] = threadIdx.x < nj ? P.sbase[j0 + threadIdx.x] : -1;
+    }
+    __syncthreads();
+    for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG) {
+        double u[TB_K];
+        bool any = false;
+#pragma unroll
+        for (int sidx = 0; sidx < TB_K; ++sidx) {
+            double x = 0.0;
+            if (sidx < np) x = eta[static_cast<size_t>(e0 + sidx) * m + p] - (p == P.pr[sidx] ? 1.0 : 0.0);
+            u[sidx] = x;
+            any = any || x != 0.0;
         }
-        if (a == 0.0) continue; // the row does not see this pivot
-        const double f = a / ar;
-        for (int64_t s = s0; s < s1; ++s) {
-            if (s == q) {
-                T[static_cast<size_t>(s) * m + p] = fabs(f) < TB_DROP ? 0.0 : -f;
-            } else {
-                const double rb_ = rowbuf[s];
-                if (rb_ != 0.0) {
-                    double *t = T + static_cast<size_t>(s) * m + p;
-                    const double v = *t - f * rb_;
-                    *t = fabs(v) < TB_DROP ? 0.0 : v; // (a tail of 1e-20s would spread the columns' supports over the whole matrix)
-                }
-            }
+        for (int jj = 0; jj < nj; ++jj) {
+            const int sb = ssb[jj];
+            if (!any && sb < 0) continue; // the row saw none of the batch's pivots and the slot keeps its column
+            double *t = T + static_cast<size_t>(j0 + jj) * m + p;
+            double acc = sb < 0 ? *t : (p == sb ? 1.0 : 0.0);
+            const int first = ss0[jj];
+#pragma unroll
+            for (int sidx = 0; sidx < TB_K; ++sidx)
+                if (sidx >= first && sidx < np) acc -= u[sidx] * vs[sidx][jj];
+            *t = fabs(acc) < TB_DROP ? 0.0 : acc;
         }
+    }
+}
+__global__ __launch_bounds__(TB_WG) void k_tb_fold_end(int64_t nJ, TbState *st, int32_t *__restrict__ s0, int32_t *__restrict__ sbase) {
+    if (!st->folding) return;
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
+    if (j < nJ) {
+        s0[j] = 0;
+        sbase[j] = -1;
+    }
+}
+__global__ void k_tb_fold_done(TbState *st) {
+    if (st->folding) {
+        st->n_pend = 0;
+        st->folding = 0;
     }
 }
 
@@ -525,17 +633,24 @@ __global__ __launch_bounds__(TB_WG) void k_tb_post(int64_t nJ, double *__restric
                                                    double *__restrict__ uB, double *__restrict__ cB, int32_t *__restrict__ varJ,
                                                    double *__restrict__ xJ, double *__restrict__ lJ, double *__restrict__ uJ,
                                                    double *__restrict__ cJ, int32_t *__restrict__ statJ, int32_t *__restrict__ eta_r,
-                                                   TbState *st) {
+                                                   TbState *st, double *__restrict__ vbuf, int64_t ldv, int32_t *__restrict__ pr,
+                                                   int32_t *__restrict__ s0, int32_t *__restrict__ sbase) {
     if (st->status != 0) return;
     const int q = st->q, r = st->r;
     const double dq = st->dq, ar = st->alpha_r;
     if (r >= 0) {
         const double f = dq / ar;
-        for (int64_t s = threadIdx.x; s < nJ; s += TB_WG)
+        const bool good = fabs(ar) > TB_PIV;
+        double *v = vbuf + static_cast<size_t>(st->n_pend) * ldv;
+        for (int64_t s = threadIdx.x; s < nJ; s += TB_WG) {
+            const double rb = rowbuf[s];
             if (s != q) {
-                const double rb = rowbuf[s];
                 if (rb != 0.0) dJ[s] = dJ[s] - f * rb;
+                if (good) v[s] = rb / ar;
+            } else if (good) {
+                v[s] = 1.0 / ar;
             }
+        }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -568,6 +683,10 @@ __global__ __launch_bounds__(TB_WG) void k_tb_post(int64_t nJ, double *__restric
     statJ[q] = st->hit == 2 ? TB_UPP : TB_LOW;
     dJ[q] = -dq / ar;
     eta_r[st->n_eta] = r;
+    pr[st->n_pend] = r;
+    s0[q] = st->n_pend; // the slot now holds the leaving variable: its column is e_r - u v[q] from this pivot on
+    sbase[q] = r;
+    st->n_pend += 1;
     st->n_eta += 1;
     st->pivots += 1;
 }
@@ -836,6 +955,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
            *d_part = nullptr, *d_infpart = nullptr, *d_vec = nullptr;
     int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr, *d_blist = nullptr;
+    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr;
+    double *d_vbuf = nullptr, *d_gu = nullptr;
     TbPart *d_rpart = nullptr;
     TbState *d_st = nullptr;
     const int nblk = static_cast<int>(gridof(m));
@@ -1009,6 +1130,11 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_TRY(dev.get(static_cast<size_t>(capJ), &d_rowbuf));
             SX_TRY(dev.get(static_cast<size_t>(capJ), &d_varJ));
             SX_TRY(dev.get(static_cast<size_t>(capJ), &d_statJ));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_s0));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_sbase));
+            SX_TRY(dev.get(static_cast<size_t>(TB_K) * capJ, &d_vbuf));
+            SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_pr));
+            SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_gu));
             // the eta file takes what is left (up to 20,000 basis changes)
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
             if (!getenv("SX_BAND_EPOCH"))
@@ -1164,6 +1290,9 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             return SX_OK;
         };
         SX_TRY(load_slots(0, varJ));
+        SX_HIP(hipMemsetAsync(d_s0, 0, sizeof(int32_t) * static_cast<size_t>(capJ), s));       // no pending update anywhere
+        SX_HIP(hipMemsetAsync(d_sbase, 0xFF, sizeof(int32_t) * static_cast<size_t>(capJ), s)); // (-1: every slot's base column is T's)
+        const TbPend pend{d_vbuf, d_pr, d_s0, d_sbase, capJ};
         if (trace) {
             SX_HIP(hipStreamSynchronize(s));
             fprintf(stderr, "[sx_crossover_band] epoch %d: basic solution and slots done at %.1f ms\n", epochs, now() - t_begin);
@@ -1188,16 +1317,24 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         auto one_pivot = [&]() {
             hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
             hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st);
-            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_infpart, d_st, d_d1);
+            hipLaunchKernelGGL(k_tb_gu, dim3(TB_K), dim3(TB_WG), 0, s, m, nblk, d_eta, d_g, d_infpart, d_st, pend, d_gu);
+            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_infpart, d_st, pend, d_gu, d_d1);
             hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
-            hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part);
+            hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part, pend);
             hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
             hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(TB_WG), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
-            hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_st, d_rowbuf);
-            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s, m, nJ, d_T, d_xB, d_eta, d_rowbuf, d_st, d_blist);
+            hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_eta, d_st, pend, d_rowbuf);
+            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64))), dim3(TB_WG), 0, s, m, d_xB, d_eta, d_st, d_blist);
             hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, d_varJ, d_xJ, d_lJ, d_uJ,
-                               d_cJ, d_statJ, d_eta_r, d_st);
+                               d_cJ, d_statJ, d_eta_r, d_st, d_vbuf, capJ, d_pr, d_s0, d_sbase);
+        };
+        auto fold = [&]() { // applies the pending batch when it is nearly full, or when the run has stopped
+            hipLaunchKernelGGL(k_tb_fold_begin, dim3(1), dim3(1), 0, s, d_st, 16);
+            hipLaunchKernelGGL(k_tb_fold, dim3(static_cast<unsigned>(std::min(nblk, 128)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s,
+                               m, nJ, d_T, d_eta, d_st, pend);
+            hipLaunchKernelGGL(k_tb_fold_end, dim3(gridof(nJ)), dim3(TB_WG), 0, s, nJ, d_st, d_s0, d_sbase);
+            hipLaunchKernelGGL(k_tb_fold_done, dim3(1), dim3(1), 0, s, d_st);
         };
         int rounds = 0;
         bool restart = false;
@@ -1206,6 +1343,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             if (nJ > 0) {
                 for (;;) {
                     for (int k = 0; k < 16; ++k) one_pivot();
+                    fold();
                     SX_HIP(hipMemcpyAsync(&hst, d_st, sizeof(hst), hipMemcpyDeviceToHost, s));
                     SX_HIP(hipStreamSynchronize(s));
                     SX_HIP(hipGetLastError());
