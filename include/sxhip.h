@@ -439,14 +439,18 @@ int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *
  * whose largest candidate pivot is <= pivot_tol is REPLACED by the unit vector of the row on its diagonal and
  * reported (replaced_host[n], host, may be NULL; ipiv_host[n] the row swapped with j at step j).  solve: nrhs
  * right-hand sides, column major with leading dimension ldx, in place; trans 0: A x = b, 1: A^T x = b (A = the
- * matrix with its replaced columns).  Limits: kl + 32 <= 1536, kl + ku + 32 <= 2400.  Blocking (factor) /
- * stream-ordered (solve); arrays device unless named host. */
+ * matrix with its replaced columns).  solve_sparse: A x = b for right-hand sides with few entries each (the columns
+ * of an LP): panels of 32 rows whose entries are all <= tiny in magnitude are skipped, in the forward sweep (before the
+ * first entry of b, and once the fill past its last entry has decayed below tiny) and in the backward sweep; tiny = 0
+ * skips exact zeros only and returns the plain solve's result.  Limits: kl + 32 <= 1536, kl + ku + 32 <= 2400.
+ * Blocking (factor) / stream-ordered (solve); arrays device unless named host. */
 typedef struct sx_bandlu sx_bandlu;
 int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
                          const double *val, sx_bandlu **out);
 int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
                          int32_t *ipiv_host);
 int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
+int sx_bandlu_solve_sparse_dev(sx_bandlu *h, int64_t nrhs, double *X, int64_t ldx, double tiny);
 int sx_bandlu_destroy(sx_bandlu *h);
 
 /* Sparse crossover (K16s, csrc/sx_crossover_band.hip): the same job as sx_simplex_crossover_dev -- from the point

@@ -35,6 +35,8 @@ struct sx_bandlu {
     int32_t *replaced = nullptr; // [n] 1: column j was replaced by a unit vector
     int32_t *err = nullptr;      // [1] scatter found an entry outside the band
     uint8_t *d_swaps = nullptr;  // [panels] 1: the panel's factorisation swapped rows
+    uint8_t *d_flags = nullptr;  // [groups][panels] of the last sparse solve (grown on demand)
+    size_t flags_cap = 0;
     bool factored = false;
     std::vector<uint8_t> panel_swaps; // [panels] 1: the panel's factorisation swapped rows (host copy)
 };
@@ -704,6 +706,100 @@ __global__ __launch_bounds__(GB_T2) void k_gb_solve_loop(double *__restrict__ ab
     }
 }
 
+// ------------------------------------------------------------------------------------------- sparse right-hand sides
+// A x = b for right-hand sides that are mostly zeros (the columns of an LP: a handful of entries each).  A panel of the
+// forward sweep whose rows hold nothing but zeros does nothing, and neither does a panel of the backward sweep; past the
+// last entry of b the forward sweep's values decay geometrically (row by row, for a factor without growth) and are
+// treated as zeros once all of a window's entries are <= tiny in magnitude.  tiny = 0: exact zeros only, the result is
+// the plain solve's.  flags[g][p] = 1: panel p of workgroup g's right-hand sides holds an entry (set by k_gb_flag for
+// b, extended by the forward sweep for what it fills in).
+__global__ __launch_bounds__(256) void k_gb_flag(int64_t n, int64_t ntgt, const double *__restrict__ X, int64_t ldx, double tiny,
+                                                 int64_t npanel, uint8_t *__restrict__ flags) {
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < n * ntgt; e += static_cast<int64_t>(gridDim.x) * 256) {
+        const int64_t t = e / n, i = e - t * n; // (grid-stride: a launch carries fewer than 2^32 work-items)
+        if (fabs(X[i + t * ldx]) > tiny) flags[(t / GB_CB) * npanel + i / GB_NB] = 1;
+    }
+}
+
+// first flagged panel in [p, npanel) (npanel if none) / last flagged panel in [0, p] (-1 if none); every wave scans for itself
+__device__ __forceinline__ int64_t gb_next_flag(const uint8_t *__restrict__ f, int64_t p, int64_t npanel) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = p; base < npanel; base += 64) {
+        const int64_t q = base + lane;
+        const unsigned long long bal = __ballot(q < npanel && f[q] != 0);
+        if (bal) return base + __ffsll(static_cast<long long>(bal)) - 1;
+    }
+    return npanel;
+}
+__device__ __forceinline__ int64_t gb_prev_flag(const uint8_t *__restrict__ f, int64_t p) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = p; base >= 0; base -= 64) {
+        const int64_t q = base - lane;
+        const unsigned long long bal = __ballot(q >= 0 && f[q] != 0);
+        if (bal) return base - (__ffsll(static_cast<long long>(bal)) - 1);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(GB_T2) void k_gb_solve_sparse(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
+                                                           const int32_t *__restrict__ ipiv, const uint8_t *__restrict__ swaps,
+                                                           int64_t ntgt, double *__restrict__ X, int64_t ldx, double tiny,
+                                                           uint8_t *__restrict__ flags) {
+    extern __shared__ double lds_raw[]; // (w[R][GB_CB] first in every body's layout)
+    const int64_t npanel = (n + GB_NB - 1) / GB_NB;
+    uint8_t *f = flags + static_cast<size_t>(blockIdx.x) * npanel;
+    const int tid = threadIdx.x;
+    const int kq = (kl + GB_NB - 1) / GB_NB; // panels a row swap can reach down
+    // ---- forward: L with the swaps
+    int active = 0;
+    int64_t p = 0;
+    while (p < npanel) {
+        if (!active) {
+            const int64_t q = gb_next_flag(f, p, npanel);
+            if (q >= npanel) break;
+            if (q - kq > p) p = q - kq;
+        }
+        const int64_t j0 = p * GB_NB;
+        const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+        if (swaps[p]) gb_apply_body<false>(ab, ldab, kl, ku, n, j0, ncol, ipiv, 0, ntgt, X, ldx);
+        else gb_lsolve2_body<false>(ab, ldab, kl, ku, n, j0, ncol, 0, ntgt, X, ldx);
+        __syncthreads();
+        const int R = static_cast<int>((n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol);
+        int any = 0, own = 0;
+        for (int e = tid; e < R * GB_CB; e += GB_T2) {
+            const int hit = fabs(lds_raw[e]) > tiny;
+            if (e >= ncol * GB_CB) any |= hit;
+            else own |= hit;
+        }
+        active = __syncthreads_or(any);
+        own = __syncthreads_or(own);
+        // what the backward sweep will find in the panel's rows
+        if (tid == 0 && own) f[p] = 1; // (the rows below are the next panels' own rows: an active sweep goes on to them)
+        __syncthreads();
+        ++p;
+    }
+    __syncthreads();
+    // ---- backward: U
+    active = 0;
+    p = npanel - 1;
+    while (p >= 0) {
+        if (!active) {
+            p = gb_prev_flag(f, p);
+            if (p < 0) break;
+        }
+        const int64_t j0 = p * GB_NB;
+        const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+        gb_usolve2_body(ab, ldab, kl, ku, n, j0, ncol, ntgt, X, ldx);
+        __syncthreads();
+        const int kw = ku + kl;
+        const int top = static_cast<int>(j0 - ((j0 - kw > 0) ? j0 - kw : 0));
+        int any = 0;
+        for (int e = tid; e < top * GB_CB; e += GB_T2) any |= fabs(lds_raw[e]) > tiny;
+        active = __syncthreads_or(any);
+        --p;
+    }
+}
+
 } // namespace
 
 SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
@@ -727,6 +823,7 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
                 (void)hipFree(h->ab);
                 (void)hipFree(h->ipiv);
                 (void)hipFree(h->d_swaps);
+                (void)hipFree(h->d_flags);
                 delete h;
             }
         }
@@ -742,6 +839,7 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
         const int cap = 150 * 1024;
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_solve_loop), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_trail2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_solve_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     }
     SX_HIP(hipMemsetAsync(h->ab, 0, bytes, s));
     SX_HIP(hipMemsetAsync(h->ipiv, 0, sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4), s));
@@ -765,6 +863,7 @@ SX_API int sx_bandlu_destroy(sx_bandlu *h) {
     (void)hipFree(h->ab);
     (void)hipFree(h->ipiv);
     (void)hipFree(h->d_swaps);
+    (void)hipFree(h->d_flags);
     delete h;
     return SX_OK;
 }
@@ -839,6 +938,38 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     (void)npanel;
     hipLaunchKernelGGL(k_gb_solve_loop, dim3(grid), dim3(GB_T2), gb_lds_bytes(kl + ku + GB_NB), s, h->ab, h->ldab, kl, ku, n, h->ipiv,
                        h->d_swaps, nrhs, X, ldx, trans ? 1 : 0, slow ? 1 : 0);
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
+// A x = b in place for nrhs right-hand sides with few entries each (see k_gb_solve_sparse): panels whose rows hold
+// nothing above `tiny` in magnitude are skipped.  tiny = 0 gives the plain solve's result; the sparse crossover passes
+// 1e-60 (46 orders below what its tableau drops).
+SX_API int sx_bandlu_solve_sparse_dev(sx_bandlu *h, int64_t nrhs, double *X, int64_t ldx, double tiny) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
+    sx_ctx *ctx = h->ctx;
+    SX_ENTER(ctx);
+    SX_REQUIRE(h->factored, "factor first");
+    SX_REQUIRE(X && ldx >= h->n && nrhs >= 0 && tiny >= 0.0, "bad right-hand side block");
+    if (nrhs == 0) return SX_OK;
+    hipStream_t s = ctx->stream;
+    const int kl = h->kl, ku = h->ku;
+    const int64_t n = h->n;
+    const int64_t groups = (nrhs + GB_CB - 1) / GB_CB, npanel = (n + GB_NB - 1) / GB_NB;
+    const size_t need = static_cast<size_t>(groups) * static_cast<size_t>(npanel);
+    if (need > h->flags_cap) {
+        SX_HIP(hipStreamSynchronize(s));
+        (void)hipFree(h->d_flags);
+        h->d_flags = nullptr;
+        h->flags_cap = 0;
+        SX_HIP(hipMalloc(&h->d_flags, need));
+        h->flags_cap = need;
+    }
+    SX_HIP(hipMemsetAsync(h->d_flags, 0, need, s));
+    hipLaunchKernelGGL(k_gb_flag, dim3(static_cast<unsigned>(std::min<int64_t>((n * nrhs + 255) / 256, 1 << 20))), dim3(256), 0, s, n, nrhs, X, ldx, tiny, npanel,
+                       h->d_flags);
+    hipLaunchKernelGGL(k_gb_solve_sparse, dim3(static_cast<unsigned>(groups)), dim3(GB_T2), gb_lds_bytes(kl + ku + GB_NB), s, h->ab, h->ldab,
+                       kl, ku, n, h->ipiv, h->d_swaps, nrhs, X, ldx, tiny, h->d_flags);
     SX_HIP(hipGetLastError());
     return SX_OK;
 }

@@ -29,6 +29,7 @@ namespace {
 constexpr int TB_WG = 256;
 constexpr int TB_SUP = 3, TB_LOW = 1, TB_UPP = 2; // status of a tracked non-basic column
 constexpr double TB_PIV = 1e-7;                   // smallest |alpha| the ratio test accepts
+constexpr double TB_TINY = 1e-60; // band solves of tableau columns treat windows below this as zeros
 constexpr double TB_DROP = 1e-14;                 // tableau entries below this become exact zeros (keeps B^-1 A_J local)
 
 struct TbState {
@@ -118,9 +119,10 @@ __device__ __forceinline__ double tb_block_sum(double v, double *sm) {
 }
 
 // entries below the drop tolerance -> exact zeros (what the pivots skip)
+// (grid-stride: a launch carries fewer than 2^32 work-items, a tableau has more entries than that)
 __global__ __launch_bounds__(TB_WG) void k_tb_drop(int64_t total, double *__restrict__ W, double tol) {
-    const int64_t t = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
-    if (t < total && fabs(W[t]) < tol) W[t] = 0.0;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; t < total; t += static_cast<int64_t>(gridDim.x) * TB_WG)
+        if (fabs(W[t]) < tol) W[t] = 0.0;
 }
 
 // out[s] = base[s] - sum_p w[p] T[p, s]        (one workgroup per tracked column)
@@ -692,48 +694,60 @@ __global__ __launch_bounds__(TB_WG) void k_tb_post(int64_t nJ, double *__restric
 }
 
 // ---------------------------------------------------------------------------------------------- eta file
-// W <- E W for ncols columns (ldw = m): W[r] /= alpha_r; W[p] -= alpha_p W[r]
-__global__ __launch_bounds__(TB_WG) void k_tb_eta_fwd(int64_t m, int64_t ncols, double *__restrict__ W,
-                                                      const double *__restrict__ alpha, const int32_t *__restrict__ eta_r,
-                                                      int64_t k) {
+// W <- E W for ncols columns (ldw = m): W[r] /= alpha_r; W[p] -= alpha_p W[r].  Most columns have no entry in row r
+// (the columns pricing adds are local, the pivots of the run were elsewhere): first the list of those that do, then
+// the update of just those.
+__global__ __launch_bounds__(TB_WG) void k_tb_eta_list(int64_t m, int64_t ncols, const double *__restrict__ W,
+                                                       const int32_t *__restrict__ eta_r, int64_t k, int32_t *__restrict__ list,
+                                                       int32_t *__restrict__ count) {
+    const int64_t s = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
+    if (s >= ncols) return;
+    if (W[static_cast<size_t>(s) * m + eta_r[k]] != 0.0) list[atomicAdd(count, 1)] = static_cast<int32_t>(s);
+}
+__global__ __launch_bounds__(TB_WG) void k_tb_eta_fwd(int64_t m, double *__restrict__ W, const double *__restrict__ alpha,
+                                                      const int32_t *__restrict__ eta_r, int64_t k, const int32_t *__restrict__ list,
+                                                      const int32_t *__restrict__ count) {
     const int r = eta_r[k];
-    const int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
-    const int64_t s = blockIdx.y;
-    if (p >= m || s >= ncols) return;
-    double *col = W + static_cast<size_t>(s) * m;
-    const double wr = col[r] / alpha[r];
-    if (wr == 0.0) return;
-    if (p != r) {
-        const double a = alpha[p];
-        if (a != 0.0) col[p] = col[p] - a * wr;
+    const int n = *count;
+    const double ar = alpha[r];
+    for (int e = blockIdx.y; e < n; e += gridDim.y) {
+        double *col = W + static_cast<size_t>(list[e]) * m;
+        const double wr = col[r] / ar; // (row r itself is rewritten by k_tb_eta_fwd_r, after every block has read it)
+        for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG)
+            if (p != r) {
+                const double a = alpha[p];
+                if (a != 0.0) col[p] = col[p] - a * wr;
+            }
     }
 }
-__global__ void k_tb_eta_fwd_r(int64_t m, int64_t ncols, double *__restrict__ W, const double *__restrict__ alpha,
-                               const int32_t *__restrict__ eta_r, int64_t k) {
+__global__ void k_tb_eta_fwd_r(int64_t m, double *__restrict__ W, const double *__restrict__ alpha, const int32_t *__restrict__ eta_r,
+                               int64_t k, const int32_t *__restrict__ list, int32_t *__restrict__ count) {
     const int r = eta_r[k];
-    const int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (s < ncols) W[static_cast<size_t>(s) * m + r] = W[static_cast<size_t>(s) * m + r] / alpha[r];
+    const int n = *count;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) W[static_cast<size_t>(list[e]) * m + r] = W[static_cast<size_t>(list[e]) * m + r] / alpha[r];
+    __syncthreads();
+    if (threadIdx.x == 0) *count = 0; // for the next eta
 }
-// v <- E^T v:  v[r] = (v[r] - sum_{p != r} alpha_p v[p]) / alpha_r;  one workgroup of 1024
-__global__ __launch_bounds__(1024) void k_tb_eta_t(int64_t m, double *__restrict__ v, const double *__restrict__ alpha,
-                                                   const int32_t *__restrict__ eta_r, int64_t k) {
-    __shared__ double sm[16];
+// v <- E^T v:  v[r] = (v[r] - sum_{p != r} alpha_p v[p]) / alpha_r; partial dots by G workgroups, summed in order
+__global__ __launch_bounds__(TB_WG) void k_tb_eta_t_part(int64_t m, const double *__restrict__ v, const double *__restrict__ alpha,
+                                                         const int32_t *__restrict__ eta_r, int64_t k, double *__restrict__ part) {
+    __shared__ double sm[4];
     const int r = eta_r[k];
     double acc = 0.0;
-    for (int64_t p = threadIdx.x; p < m; p += 1024)
+    for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG)
         if (p != r) {
             const double a = alpha[p];
             if (a != 0.0) acc += a * v[p];
         }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += sm[w];
-        v[r] = (v[r] - t) / alpha[r];
-    }
+    const double tot = tb_block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ void k_tb_eta_t_fin(int G, double *__restrict__ v, const double *__restrict__ alpha, const int32_t *__restrict__ eta_r, int64_t k,
+                               const double *__restrict__ part) {
+    const int r = eta_r[k];
+    double t = 0.0;
+    for (int g = 0; g < G; ++g) t += part[g];
+    v[r] = (v[r] - t) / alpha[r];
 }
 
 struct DevBufs {
@@ -767,6 +781,7 @@ int down(hipStream_t s, std::vector<T> &dst, const T *src, size_t count) {
 }
 
 inline unsigned gridof(int64_t n) { return static_cast<unsigned>(n > 0 ? (n + TB_WG - 1) / TB_WG : 1); }
+inline unsigned gridcap(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(gridof(n), 1 << 20)); } // for grid-stride kernels
 
 } // namespace
 
@@ -780,6 +795,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     const int64_t m = A->m, n = A->n;
     SX_REQUIRE(m > 0 && n > 0 && m + n < 2000000000LL, "problem size");
     const bool trace = getenv("SX_SPX_TRACE") != nullptr;
+    const bool dense_solves = getenv("SX_BAND_DENSE_SOLVES") != nullptr; // A/B: tableau columns through the plain band solve
     hipStream_t s = ctx->stream;
     auto now = []() {
         timespec ts;
@@ -955,7 +971,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
            *d_part = nullptr, *d_infpart = nullptr, *d_vec = nullptr;
     int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr, *d_blist = nullptr;
-    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr;
+    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr, *d_elist = nullptr, *d_elist_n = nullptr;
     double *d_vbuf = nullptr, *d_gu = nullptr;
     TbPart *d_rpart = nullptr;
     TbState *d_st = nullptr;
@@ -1135,6 +1151,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_TRY(dev.get(static_cast<size_t>(TB_K) * capJ, &d_vbuf));
             SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_pr));
             SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_gu));
+            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_elist));
+            SX_TRY(dev.get(4, &d_elist_n));
             // the eta file takes what is left (up to 20,000 basis changes)
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
             if (!getenv("SX_BAND_EPOCH"))
@@ -1199,12 +1217,21 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         // solve helper: position-space vectors through B0 (band part + dense rows), then the eta file
         auto ftran_cols = [&](double *W, int64_t ncols, int64_t n_eta_now) -> int {
             if (ncols == 0) return SX_OK;
-            if (lu) SX_TRY(sx_bandlu_solve_dev(lu, 0, ncols, W, m));
+            if (lu) { // tableau columns are columns of A: a few entries each (TB_TINY: sx_bandlu_solve_sparse_dev)
+                if (ncols > 1 && !dense_solves) SX_TRY(sx_bandlu_solve_sparse_dev(lu, ncols, W, m, TB_TINY));
+                else SX_TRY(sx_bandlu_solve_dev(lu, 0, ncols, W, m));
+            }
             if (ndr) hipLaunchKernelGGL(k_tb_dense_rows, dim3(gridof(ndr * ncols)), dim3(TB_WG), 0, s, ndr, ncols, d_b21ptr, d_b21pos, d_b21val, W, m, m1);
+            if (n_eta_now > 0) { // (what the tableau would drop anyway goes first: the list of an eta holds real entries only)
+                hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(m * ncols)), dim3(TB_WG), 0, s, m * ncols, W, TB_DROP);
+                SX_HIP(hipMemsetAsync(d_elist_n, 0, sizeof(int32_t), s));
+            }
             for (int64_t k = 0; k < n_eta_now; ++k) {
-                hipLaunchKernelGGL(k_tb_eta_fwd, dim3(gridof(m), static_cast<unsigned>(ncols)), dim3(TB_WG), 0, s, m, ncols, W,
-                                   d_eta + static_cast<size_t>(k) * m, d_eta_r, k);
-                hipLaunchKernelGGL(k_tb_eta_fwd_r, dim3(gridof(ncols)), dim3(TB_WG), 0, s, m, ncols, W, d_eta + static_cast<size_t>(k) * m, d_eta_r, k);
+                const double *al = d_eta + static_cast<size_t>(k) * m;
+                hipLaunchKernelGGL(k_tb_eta_list, dim3(gridof(ncols)), dim3(TB_WG), 0, s, m, ncols, W, d_eta_r, k, d_elist, d_elist_n);
+                hipLaunchKernelGGL(k_tb_eta_fwd, dim3(static_cast<unsigned>(std::min(nblk, 64)), 8), dim3(TB_WG), 0, s, m, W, al, d_eta_r, k, d_elist,
+                                   d_elist_n);
+                hipLaunchKernelGGL(k_tb_eta_fwd_r, dim3(1), dim3(TB_WG), 0, s, m, W, al, d_eta_r, k, d_elist, d_elist_n);
             }
             SX_HIP(hipGetLastError());
             return SX_OK;
@@ -1283,7 +1310,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_HIP(hipMemsetAsync(W, 0, sizeof(double) * static_cast<size_t>(m) * k, s));
             hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(k)), dim3(TB_WG), 0, s, k, d_varJ + s0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, W, m);
             SX_TRY(ftran_cols(W, k, n_eta_now));
-            hipLaunchKernelGGL(k_tb_drop, dim3(gridof(m * k)), dim3(TB_WG), 0, s, m * k, W, 10.0 * TB_DROP);
+            hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(m * k)), dim3(TB_WG), 0, s, m * k, W, 10.0 * TB_DROP);
             // reduced costs of the new columns under the current basis: d = c_J - c_B^T T
             hipLaunchKernelGGL(k_tb_coldot, dim3(static_cast<unsigned>(k)), dim3(TB_WG), 0, s, m, W, d_cB, d_cJ + s0, d_dJ + s0);
             SX_HIP(hipGetLastError());
@@ -1369,11 +1396,16 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             //      infeasibility's (g on the basic variables, nothing elsewhere)
             const bool ph1 = hst.phase == 1;
             SX_HIP(hipMemcpyAsync(d_vec, ph1 ? d_g : d_cB, sizeof(double) * static_cast<size_t>(m), hipMemcpyDeviceToDevice, s));
-            for (int64_t k = hst.n_eta - 1; k >= 0; --k)
-                hipLaunchKernelGGL(k_tb_eta_t, dim3(1), dim3(1024), 0, s, m, d_vec, d_eta + static_cast<size_t>(k) * m, d_eta_r, k);
+            const int etg = std::min(nblk, 64);
+            for (int64_t k = hst.n_eta - 1; k >= 0; --k) {
+                const double *al = d_eta + static_cast<size_t>(k) * m;
+                hipLaunchKernelGGL(k_tb_eta_t_part, dim3(static_cast<unsigned>(etg)), dim3(TB_WG), 0, s, m, d_vec, al, d_eta_r, k, d_part);
+                hipLaunchKernelGGL(k_tb_eta_t_fin, dim3(1), dim3(1), 0, s, etg, d_vec, al, d_eta_r, k, d_part);
+            }
             std::vector<double> hv;
             SX_TRY(down(s, hv, d_vec, static_cast<size_t>(m)));
             SX_HIP(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: eta file transposed (%lld etas) by %.1f ms\n", rounds, (long long)hst.n_eta, now() - t_begin);
             // B0^T y = v:  y2 = v2;  B11^T y1 = v1 - B21^T y2
             for (int64_t k = 0; k < ndr; ++k) {
                 const double y2 = hv[m1 + k];
@@ -1402,6 +1434,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_TRY(down(s, hvarJ, d_varJ, static_cast<size_t>(nJ)));
             SX_TRY(down(s, hstatJ, d_statJ, static_cast<size_t>(nJ)));
             SX_HIP(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: duals and reduced costs by %.1f ms\n", rounds, now() - t_begin);
             std::fill(vstat.begin(), vstat.end(), 0);
             for (int64_t p = 0; p < m; ++p) vstat[hh[p]] = 1;
             for (int64_t t = 0; t < nJ; ++t) vstat[hvarJ[t]] = 2;
@@ -1439,6 +1472,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             hst.status = 0;
             SX_HIP(hipMemcpyAsync(d_st, &hst, sizeof(hst), hipMemcpyHostToDevice, s)); // (status only changed; counters as read)
             SX_HIP(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: %lld columns brought into the tableau by %.1f ms\n", rounds, (long long)take, now() - t_begin);
         }
         // ---------------------------------------------------------------- the epoch's end state -> host
         std::vector<int32_t> hh, hvarJ, hstatJ;

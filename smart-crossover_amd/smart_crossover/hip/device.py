@@ -351,6 +351,10 @@ class BandLU:
     def solve(self, X: "DeviceArray", nrhs: int = 1, ldx: Optional[int] = None, trans: bool = False) -> None:
         _l.check(self.ctx._lib.sx_bandlu_solve_dev(self.handle, int(bool(trans)), int(nrhs), X.ptr, int(ldx or self.n)))
 
+    def solve_sparse(self, X: "DeviceArray", nrhs: int = 1, ldx: Optional[int] = None, tiny: float = 0.0) -> None:
+        """A x = b for right-hand sides with few entries: panels holding nothing above `tiny` are skipped."""
+        _l.check(self.ctx._lib.sx_bandlu_solve_sparse_dev(self.handle, int(nrhs), X.ptr, int(ldx or self.n), float(tiny)))
+
     def free(self) -> None:
         if self.handle is not None:
             self.ctx._lib.sx_bandlu_destroy(self.handle)

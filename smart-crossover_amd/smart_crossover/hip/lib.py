@@ -135,6 +135,7 @@ PROTOTYPES = {
     "sx_bandlu_create_dev": (_int, [_vp, _i64, _int, _int, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "sx_bandlu_factor_dev": (_int, [_vp, _dbl, C.POINTER(_i64), _vp, _vp]),
     "sx_bandlu_solve_dev": (_int, [_vp, _int, _i64, _vp, _i64]),
+    "sx_bandlu_solve_sparse_dev": (_int, [_vp, _i64, _vp, _i64, _dbl]),
     "sx_bandlu_destroy": (_int, [_vp]),
     "sx_netsimplex_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  C.POINTER(SimplexResult)]),

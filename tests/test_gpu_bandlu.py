@@ -110,3 +110,56 @@ def test_entries_outside_the_band_are_refused(ctx):
     put = lambda v, t: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
     with pytest.raises(Exception):
         BandLU(ctx, 10, 1, 1, put([0, 5], np.int32), put([0, 1], np.int32), put([1.0, 2.0], np.float64))
+
+
+def dominant_band(n, kl, ku, seed, swaps):
+    """A band matrix whose inverse decays away from the diagonal (own entry ~1, the others small), as the bases of the
+    sparse crossover are; `swaps`: a tenth of the rows change places with their neighbour below, so that the
+    factorisation has to swap them back (same conditioning; one more sub- and super-diagonal)."""
+    rng = np.random.default_rng(seed)
+    i = np.repeat(np.arange(n), kl + ku + 1)
+    j = i + np.tile(np.arange(-kl, ku + 1), n)
+    keep = (j >= 0) & (j < n) & ((rng.random(i.size) < min(0.2, 12.0 / (kl + ku))) | (i == j))   # ~12 small entries per row
+    i, j = i[keep], j[keep]
+    v = rng.uniform(-0.1, 0.1, i.size)
+    v[i == j] = rng.uniform(0.8, 1.2, int((i == j).sum()))
+    if swaps:
+        perm = np.arange(n)
+        for r in np.flatnonzero(rng.random(n - 1) < 0.1)[::2]:
+            if perm[r] == r and perm[r + 1] == r + 1:
+                perm[r], perm[r + 1] = r + 1, r
+        i = perm[i]
+    return sp.coo_matrix((v, (i, j)), shape=(n, n)).tocsr()
+
+
+@pytest.mark.parametrize("swaps", [False, True])
+@pytest.mark.parametrize("n,kl,ku", [(6000, 40, 30), (20000, 117, 113)])
+def test_sparse_right_hand_sides(ctx, n, kl, ku, swaps):
+    """solve_sparse (panels without entries skipped): with tiny = 0 the plain solve's result bit for bit, with the
+    crossover's 1e-60 equal to 1e-50; right-hand sides with entries in one place, in two far apart, at both ends, none."""
+    A = dominant_band(n, kl, ku, 5, swaps)
+    kl, ku = kl + int(swaps), ku + int(swaps)
+    lu, rep, piv = factor(ctx, A, kl, ku)
+    assert rep.sum() == 0 and np.any(piv != np.arange(n)) == swaps
+    rng = np.random.default_rng(6)
+    nrhs = 27
+    B = np.zeros((n, nrhs))
+    for t in range(nrhs - 4):
+        at = rng.integers(0, n)
+        rows = np.clip(at + rng.integers(-20, 21, 6), 0, n - 1)
+        B[rows, t] = rng.uniform(-1, 1, 6)
+    B[[3, n - 2], nrhs - 4] = [1.0, -2.0]            # both ends
+    B[[n // 5, 4 * n // 5], nrhs - 3] = [0.5, 0.25]  # two places far apart
+    B[n - 1, nrhs - 2] = 1.0                         # the last row only; the last right-hand side stays empty
+    ref = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+    lu.solve(ref, nrhs, n, False)
+    want = ref.download().reshape((n, nrhs), order="F")
+    Ad = sp.csc_matrix(A)
+    assert np.abs(Ad @ want - B).max() <= 1e-12
+    for tiny, tol in ((0.0, 0.0), (1e-60, 1e-50)):
+        X = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+        lu.solve_sparse(X, nrhs, n, tiny)
+        got = X.download().reshape((n, nrhs), order="F")
+        assert np.abs(got - want).max() <= tol, tiny
+    assert np.all(want[:, nrhs - 1] == 0.0)
+    lu.free()
