@@ -73,6 +73,8 @@ struct GbPanelShared {
     double rv[T / 64];
     int ri[T / 64];
     int s_p;
+    int piv[GB_NB], rep[GB_NB]; // the panel's pivot rows / replaced flags: to global memory once, at the end (a store
+                                // ahead of a barrier makes the barrier wait for the store's acknowledgement: ~1 us a column)
 };
 
 // one column step of the panel, C a compile-time constant so that v[][C] stays in registers
@@ -121,8 +123,8 @@ __device__ __forceinline__ void gb_panel_step(double (&v)[RPT][GB_NB], GbPanelSh
             }
         const bool bad = !(b > tol); // (NaN counts as unusable)
         sh.s_p = bad ? -1 : i;
-        ipiv[j0 + c] = static_cast<int32_t>(j0 + (bad ? c : i));
-        replaced[j0 + c] = bad ? 1 : 0;
+        sh.piv[c] = bad ? c : i;
+        sh.rep[c] = bad ? 1 : 0;
     }
     __syncthreads();
     const int p = sh.s_p;
@@ -219,6 +221,11 @@ __global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int lda
         }
     }
     GbPanelSteps<T, RPT, 0>::run(v, sh, ab, ldab, kl, ku, j0, ncol, R, tol, ipiv, replaced);
+    __syncthreads();
+    if (tid < ncol) {
+        ipiv[j0 + tid] = static_cast<int32_t>(j0 + sh.piv[tid]);
+        replaced[j0 + tid] = sh.rep[tid];
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int rho = tid + k * T;
