@@ -64,15 +64,35 @@ __global__ __launch_bounds__(256) void k_gb_scatter(int64_t nnz, const int32_t *
     AB(ab, ldab, kl, ku, i, j) = val[t]; // (duplicates are the caller's business: last writer wins)
 }
 
+// maximum of a 64-bit key over the 64 lanes of a wave, in every lane: DPP moves (quad swaps, row rotations, the two row
+// broadcasts), no LDS traffic -- __shfl_down on a double and an int costs three ds_bpermute round trips per stage
+template <int CTRL>
+__device__ __forceinline__ unsigned long long gb_dpp_max(unsigned long long k) {
+    const int lo = static_cast<int>(static_cast<unsigned>(k)), hi = static_cast<int>(static_cast<unsigned>(k >> 32));
+    const unsigned olo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+    const unsigned ohi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false));
+    const unsigned long long o = (static_cast<unsigned long long>(ohi) << 32) | olo;
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long gb_wave_max(unsigned long long k) {
+    k = gb_dpp_max<0xb1>(k);  // quad_perm [1,0,3,2]
+    k = gb_dpp_max<0x4e>(k);  // quad_perm [2,3,0,1]
+    k = gb_dpp_max<0x124>(k); // row_ror 4
+    k = gb_dpp_max<0x128>(k); // row_ror 8: every lane holds its row's maximum
+    k = gb_dpp_max<0x142>(k); // row_bcast 15: rows 1..3 take in the row before them
+    k = gb_dpp_max<0x143>(k); // row_bcast 31: lane 63 holds the wave's maximum
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<unsigned>(k)), 63));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<unsigned>(k >> 32)), 63));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------- panel
 // Rows j0 .. j0 + R - 1 of the panel's columns j0 .. j0 + ncol - 1, a row per lane and slot: lane t holds rows
 // t, t + T, ... (RPT of them).  LDS: the two rows of a swap, the reduction of the arg-max.
 template <int T, int RPT>
 struct GbPanelShared {
     double sA[GB_NB], sB[GB_NB];
-    double rv[T / 64];
-    int ri[T / 64];
-    int s_p;
+    unsigned long long key[GB_NB]; // per column: the winning arg-max key (zeroed when the kernel starts)
     int piv[GB_NB], rep[GB_NB]; // the panel's pivot rows / replaced flags: to global memory once, at the end (a store
                                 // ahead of a barrier makes the barrier wait for the store's acknowledgement: ~1 us a column)
 };
@@ -85,49 +105,30 @@ __device__ __forceinline__ void gb_panel_step(double (&v)[RPT][GB_NB], GbPanelSh
     constexpr int c = C;
     const int tid = threadIdx.x;
     if (c >= ncol) return; // uniform
-    // ---- arg-max of |a(rho, c)| over rho in [c, min(c + kl, R - 1)], ties to the smaller row
-    double best = -1.0;
-    int bi = 0x7fffffff;
+    // ---- arg-max of |a(rho, c)| over rho in [c, min(c + kl, R - 1)], ties to the smaller row: ONE 64-bit key per row,
+    //      the value's bits with the low 11 replaced by 2047 - rho (values that agree to 2^-41 count as tied), reduced
+    //      inside a wave by DPP moves (no LDS round trips) and across the waves by one LDS atomic per wave
+    unsigned long long key = 0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int rho = tid + k * T;
         if (rho >= c && rho <= c + kl && rho < R) {
-            const double a = fabs(v[k][c]);
-            if (a > best) {
-                best = a;
-                bi = rho;
-            }
+            const unsigned long long kk = (static_cast<unsigned long long>(__double_as_longlong(fabs(v[k][c]))) & ~0x7FFull) |
+                                          static_cast<unsigned long long>(2047 - rho);
+            key = kk > key ? kk : key;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_down(best, o, 64);
-        const int oi = __shfl_down(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-            best = ob;
-            bi = oi;
-        }
-    }
-    if ((tid & 63) == 0) {
-        sh.rv[tid >> 6] = best;
-        sh.ri[tid >> 6] = bi;
-    }
+    key = gb_wave_max(key);
+    if ((tid & 63) == 0) atomicMax(&sh.key[c], key);
     __syncthreads();
+    key = sh.key[c];
+    const int p_row = 2047 - static_cast<int>(key & 0x7FFull);
+    const bool bad = !(__longlong_as_double(static_cast<long long>(key & ~0x7FFull)) > tol); // (NaN counts as unusable)
     if (tid == 0) {
-        double b = sh.rv[0];
-        int i = sh.ri[0];
-        for (int w = 1; w < T / 64; ++w)
-            if (sh.rv[w] > b || (sh.rv[w] == b && sh.ri[w] < i)) {
-                b = sh.rv[w];
-                i = sh.ri[w];
-            }
-        const bool bad = !(b > tol); // (NaN counts as unusable)
-        sh.s_p = bad ? -1 : i;
-        sh.piv[c] = bad ? c : i;
+        sh.piv[c] = bad ? c : p_row;
         sh.rep[c] = bad ? 1 : 0;
     }
-    __syncthreads();
-    const int p = sh.s_p;
+    const int p = bad ? -1 : p_row;
     if (p < 0) {
         // no usable pivot: the column becomes the unit vector of the row on its diagonal
 #pragma unroll
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int lda
     const int64_t R64 = (n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol;
     const int R = static_cast<int>(R64);
     double v[RPT][GB_NB];
+    if (tid < GB_NB) sh.key[tid] = 0; // (the first barrier of the first column step comes before any read)
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int rho = tid + k * T;
@@ -382,6 +385,31 @@ __device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int
     }
 }
 
+// The 32 x 32 triangle of a panel against one right-hand side held in registers, column by column ("right-looking"):
+// x_c is final when its turn comes, the other unknowns take its term at once -- 31 - c independent multiply-subtracts
+// per step instead of one chain per unknown.  M(cc, c) = blk[cc][c], or blk[c][cc] with TRANS; FWD: c ascending, the
+// rows after c are updated (L, U^T); else c descending, the rows before c (U, L^T); DIAG: divide by blk[c][c] (U).
+// The barriers keep the compiler from gathering all 496 LDS loads at the top (it did: 2.5 KB of spills per lane).
+template <bool FWD, bool TRANS, bool DIAG>
+__device__ __forceinline__ void gb_triangle(double (&xs)[GB_NB], const double *blk, int ncol) { // (no __restrict__: it would let the loads cross the barriers)
+#pragma unroll
+    for (int s = 0; s < GB_NB; ++s) {
+        const int c = FWD ? s : GB_NB - 1 - s;
+        if (DIAG) {
+            if (c < ncol) xs[c] = xs[c] / blk[c * (GB_NB + 1) + c];
+        }
+        const double xc = xs[c];
+#pragma unroll
+        for (int cc = 0; cc < GB_NB; ++cc)
+            if (FWD ? cc > c : cc < c) {
+                xs[cc] = xs[cc] - (TRANS ? blk[c * (GB_NB + 1) + cc] : blk[cc * (GB_NB + 1) + c]) * xc;
+                asm volatile("" : "+v"(xs[cc])); // (the step's arithmetic stays in the step: without, all of it sank below the loads)
+            }
+        asm volatile("" ::: "memory"); // (a scheduling barrier alone does not do it: the loads are gathered before instruction selection)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // U x = b, panel j0: rows i0 = max(0, j0 - ku - kl) .. j0 + ncol - 1
 __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                       int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
@@ -400,39 +428,33 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
         double xs[GB_NB];
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] : 0.0;
-#pragma unroll
-        for (int c = GB_NB - 1; c >= 0; --c) {
-            if (c < ncol) {
-                double x = xs[c];
-#pragma unroll
-                for (int cc = c + 1; cc < GB_NB; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * xs[cc]; // (blk is zero beyond ncol)
-                xs[c] = x / L.blk[c * (GB_NB + 1) + c];
-            }
-        }
+        gb_triangle<false, false, true>(xs, L.blk, ncol); // (blk is zero beyond ncol)
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c)
             if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
     }
     __syncthreads();
-    // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c
-    for (int rho = tid; rho < top; rho += GB_T2) {
-        const int64_t i = i0 + rho;
-        double acc[GB_CB];
+    // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c.  A lane per (row, right-hand side): the 32 values of the panel
+    // for its right-hand side stay in registers (a lane per row with all 8 right-hand sides kept 256 of them live:
+    // 2.5 KB of spills per lane), the row's 32 entries of U are loaded first, then the arithmetic
+    {
+        const int k = tid & (GB_CB - 1), rl = tid / GB_CB;
+        double xp[GB_NB];
 #pragma unroll
-        for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
-        double av[GB_NB]; // the row's 32 entries of U first (independent loads in flight together), then the arithmetic
+        for (int c = 0; c < GB_NB; ++c) xp[c] = L.w[(top + c) * GB_CB + k];
+        for (int rho = rl; rho < top; rho += GB_T2 / GB_CB) {
+            const int64_t i = i0 + rho;
+            double av[GB_NB];
 #pragma unroll
-        for (int c = 0; c < GB_NB; ++c) {
-            const int64_t j = j0 + c;
-            av[c] = (c < ncol && i >= j - kw) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
+            for (int c = 0; c < GB_NB; ++c) {
+                const int64_t j = j0 + c;
+                av[c] = (c < ncol && i >= j - kw) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
+            }
+            double acc = L.w[rho * GB_CB + k];
+#pragma unroll
+            for (int c = 0; c < GB_NB; ++c) acc -= av[c] * xp[c];
+            L.w[rho * GB_CB + k] = acc;
         }
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) {
-#pragma unroll
-            for (int k = 0; k < GB_CB; ++k) acc[k] -= av[c] * L.w[(top + c) * GB_CB + k];
-        }
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
     }
     __syncthreads();
     for (int k = 0; k < GB_CB; ++k)
@@ -473,33 +495,27 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
         double xs[GB_NB];
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] : 0.0;
-#pragma unroll
-        for (int c = 1; c < GB_NB; ++c) {
-            double x = xs[c];
-#pragma unroll
-            for (int cc = 0; cc < c; ++cc) x -= L.blk[c * (GB_NB + 1) + cc] * xs[cc]; // (blk is zero outside the panel)
-            xs[c] = x;
-        }
+        gb_triangle<true, false, false>(xs, L.blk, ncol); // (blk is zero outside the panel)
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c)
             if (c < lim) L.w[c * GB_CB + tid] = xs[c];
     }
     __syncthreads();
-    for (int rho = ncol + tid; rho < R; rho += GB_T2) { // rows below the panel
-        double acc[GB_CB];
+    { // rows below the panel: a lane per (row, right-hand side), the panel's 32 values for the right-hand side in registers
+        const int k = tid & (GB_CB - 1), rl = tid / GB_CB;
+        double xp[GB_NB];
 #pragma unroll
-        for (int k = 0; k < GB_CB; ++k) acc[k] = L.w[rho * GB_CB + k];
-        double av[GB_NB];
+        for (int c = 0; c < GB_NB; ++c) xp[c] = L.w[c * GB_CB + k];
+        for (int rho = ncol + rl; rho < R; rho += GB_T2 / GB_CB) {
+            double av[GB_NB];
 #pragma unroll
-        for (int c = 0; c < GB_NB; ++c)
-            av[c] = (c < ncol && rho <= c + kl) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
+            for (int c = 0; c < GB_NB; ++c)
+                av[c] = (c < ncol && rho <= c + kl) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
+            double acc = L.w[rho * GB_CB + k];
 #pragma unroll
-        for (int c = 0; c < GB_NB; ++c) {
-#pragma unroll
-            for (int k = 0; k < GB_CB; ++k) acc[k] -= av[c] * L.w[c * GB_CB + k];
+            for (int c = 0; c < GB_NB; ++c) acc -= av[c] * xp[c];
+            L.w[rho * GB_CB + k] = acc;
         }
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) L.w[rho * GB_CB + k] = acc[k];
     }
     __syncthreads();
     for (int k = 0; k < GB_CB; ++k) {
@@ -572,15 +588,7 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
         double xs[GB_NB];
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) {
-            if (c < ncol) {
-                double x = xs[c];
-#pragma unroll
-                for (int cc = 0; cc < c; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * xs[cc];
-                xs[c] = x / L.blk[c * (GB_NB + 1) + c];
-            }
-        }
+        gb_triangle<true, true, true>(xs, L.blk, ncol);
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c)
             if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
@@ -643,13 +651,7 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
         double xs[GB_NB];
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
-#pragma unroll
-        for (int c = GB_NB - 2; c >= 0; --c) {
-            double x = xs[c];
-#pragma unroll
-            for (int cc = c + 1; cc < GB_NB; ++cc) x -= L.blk[cc * (GB_NB + 1) + c] * xs[cc]; // (blk is zero outside the panel)
-            xs[c] = x;
-        }
+        gb_triangle<false, true, false>(xs, L.blk, ncol); // (blk is zero outside the panel)
 #pragma unroll
         for (int c = 0; c < GB_NB; ++c)
             if (c < lim) L.w[c * GB_CB + tid] = xs[c];
