@@ -47,6 +47,23 @@ constexpr int GB_NB = 32; // panel width
 constexpr int GB_CB = 8;  // target columns per workgroup of the apply / solve kernels
 constexpr int GB_T2 = 256;
 
+// -DSX_GB_TICKS: workgroup 0's lane 0 adds the 10 ns ticks between the marks of the solve bodies to g_gb_t[] (printed by
+// the solve entry points): where a panel's step spends its time
+#ifdef SX_GB_TICKS
+__device__ unsigned long long g_gb_t[16];
+__device__ unsigned long long g_gb_last;
+#define GB_TICK(k)                                                       \
+    do {                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                       \
+            const unsigned long long now_ = wall_clock64();              \
+            g_gb_t[k] += now_ - g_gb_last;                               \
+            g_gb_last = now_;                                            \
+        }                                                                \
+    } while (0)
+#else
+#define GB_TICK(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ double &AB(double *ab, int ldab, int kl, int ku, int64_t i, int64_t j) {
     return ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
 }
@@ -356,9 +373,13 @@ __device__ __forceinline__ void gb_ltsolve_body(const double *__restrict__ ab, i
 // ------------------------------------------------------------------------------------------- phase-split solves
 // The kernels above walk a panel column by column (32 steps, a barrier or two each: 27-112 us per launch).  For a
 // dense right-hand-side block the work of a panel splits into (i) a 32 x 32 triangular solve inside the panel -- the
-// panel's own block staged in LDS, one lane per right-hand side -- and (ii) one pass that combines the rows outside
-// the panel with the panel's 32 entries at once; no step depends on another inside (ii).  Forward / backward with L
-// need the panel to be free of row swaps (the host knows: ipiv), else the step-by-step kernels run.
+// panel's own block staged in LDS, a lane per (unknown, right-hand side) -- and (ii) one pass that combines the rows
+// outside the panel with the panel's 32 entries at once; no step depends on another inside (ii).  Forward / backward
+// with L need the panel to be free of row swaps (the host knows: ipiv), else the step-by-step kernels run.
+// A panel's step is a chain of latencies (one workgroup, one panel after the other: -DSX_GB_TICKS shows 4 us of loads,
+// 2-3 us of triangle and 9-16 us in (ii) when its loads came one pass after the other), so everything a step reads from
+// HBM is asked for in ONE round at its start: the window of the right-hand sides, the panel's own block and the
+// factor's entries outside the panel that (ii) needs (GB_NPF passes of 64 rows, 8 entries per lane and pass).
 // LDS: w[R][8] | blk[32][33] | pa[32][8][8] | part[32][8]
 struct GbLds {
     double *w, *blk, *pa, *part;
@@ -385,28 +406,110 @@ __device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int
     }
 }
 
-// The 32 x 32 triangle of a panel against one right-hand side held in registers, column by column ("right-looking"):
-// x_c is final when its turn comes, the other unknowns take its term at once -- 31 - c independent multiply-subtracts
-// per step instead of one chain per unknown.  M(cc, c) = blk[cc][c], or blk[c][cc] with TRANS; FWD: c ascending, the
-// rows after c are updated (L, U^T); else c descending, the rows before c (U, L^T); DIAG: divide by blk[c][c] (U).
-// The barriers keep the compiler from gathering all 496 LDS loads at the top (it did: 2.5 KB of spills per lane).
+// The NEXT panel's part of the factor into L2 while this one is worked on: one load per 128-byte line of the entries
+// [off0, off0 + cnt) (band storage) of the columns jn0 .. jn0 + 31.  The sum only keeps the loads alive: the caller
+// hands it to gb_keep at the END of its step, so that nothing waits for these loads before the step's own work is done.
+__device__ __forceinline__ double gb_warm(const double *__restrict__ ab, int ldab, int64_t n, int64_t jn0, int off0, int cnt) {
+    double acc = 0.0;
+    const int lines = (cnt + 15) / 16;
+    for (int e = threadIdx.x; e < GB_NB * lines; e += GB_T2) {
+        const int c = e / lines, l = e - c * lines;
+        const int64_t j = jn0 + c;
+        const int o = (l * 16 < cnt - 1) ? l * 16 : cnt - 1;
+        if (j >= 0 && j < n) acc += ab[static_cast<size_t>(j) * ldab + off0 + o];
+    }
+    return acc;
+}
+__device__ __forceinline__ void gb_keep(double v) { asm volatile("" ::"v"(v)); }
+
+// The 32 x 32 triangle of a panel, a lane per (unknown r, right-hand side): wave w holds the right-hand sides 2 w and
+// 2 w + 1 in its two halves.  Column by column: x_c is final when its turn comes (after the multiplication by the
+// reciprocal of the diagonal with DIAG) and goes to the 32 lanes of its right-hand side through v_readlane -- no LDS
+// round trip in the chain --, every other unknown takes its term at once.  M(r, c) = blk[r][c], or blk[c][r] with TRANS;
+// FWD: c ascending, the unknowns after c are updated (L, U^T); else c descending, those before c (U, L^T).  x: the
+// lane's entry of the right-hand side in, of the solution out.  (One lane per right-hand side with the 32 unknowns in
+// registers was a chain of 32 x ~350 cycles and, with its 496 LDS loads gathered at the top by the compiler, 2.5 KB of
+// spills per lane; a division inside the chain costs ~200 cycles a step.)
 template <bool FWD, bool TRANS, bool DIAG>
-__device__ __forceinline__ void gb_triangle(double (&xs)[GB_NB], const double *blk, int ncol) { // (no __restrict__: it would let the loads cross the barriers)
+__device__ __forceinline__ double gb_triangle_wave(double x, const double *blk, int ncol) {
+    const int lane = threadIdx.x & 63, r = lane & 31;
+    const bool upper = lane >= 32;
+    double m[GB_NB];
+#pragma unroll
+    for (int c = 0; c < GB_NB; ++c) m[c] = TRANS ? blk[c * (GB_NB + 1) + r] : blk[r * (GB_NB + 1) + c];
+    double dinv = 1.0;
+    if (DIAG) {
+        if (r < ncol) dinv = 1.0 / blk[r * (GB_NB + 1) + r];
+    }
 #pragma unroll
     for (int s = 0; s < GB_NB; ++s) {
         const int c = FWD ? s : GB_NB - 1 - s;
         if (DIAG) {
-            if (c < ncol) xs[c] = xs[c] / blk[c * (GB_NB + 1) + c];
+            if (r == c) x = x * dinv;
         }
-        const double xc = xs[c];
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        const double x0 = __hiloint2double(__builtin_amdgcn_readlane(hi, c), __builtin_amdgcn_readlane(lo, c));
+        const double x1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32 + c), __builtin_amdgcn_readlane(lo, 32 + c));
+        const double xc = upper ? x1 : x0;
+        if (FWD ? r > c : r < c) x = x - m[c] * xc;
+    }
+    return x;
+}
+
+// (ii) for the forward / backward sweeps: w[rho] -= sum_c F(rho, c) x_c over the rows rho0 + [0, nrows) outside the panel.
+// Lane = (64 rows per pass) x (a quarter of the 32 columns): 8 entries of the factor per lane and pass -- those of the
+// first GB_NPF passes are in `pre` already, loaded at the step's start --, all 8 right-hand sides; the four quarters meet
+// through two DPP quad swaps.  xrow: LDS row of x_0.  entry(rho, c) loads F (0.0 outside the band / panel).
+constexpr int GB_NPF = 4;
+__device__ __forceinline__ double gb_quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0xb1, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0xb1, 0xf, 0xf, false));
+    v = v + o; // lanes 2q and 2q + 1 add the same two numbers: the same sum in both
+    lo = __double2loint(v), hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x4e, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0x4e, 0xf, 0xf, false));
+    return v + o;
+}
+template <class Entry>
+__device__ __forceinline__ void gb_prefetch(double (&pre)[GB_NPF][8], int rho0, int nrows, Entry entry) {
+    const int cq = threadIdx.x & 3, rq = threadIdx.x >> 2;
 #pragma unroll
-        for (int cc = 0; cc < GB_NB; ++cc)
-            if (FWD ? cc > c : cc < c) {
-                xs[cc] = xs[cc] - (TRANS ? blk[c * (GB_NB + 1) + cc] : blk[cc * (GB_NB + 1) + c]) * xc;
-                asm volatile("" : "+v"(xs[cc])); // (the step's arithmetic stays in the step: without, all of it sank below the loads)
-            }
-        asm volatile("" ::: "memory"); // (a scheduling barrier alone does not do it: the loads are gathered before instruction selection)
-        __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < GB_NPF; ++it) {
+        const int rr = rq + 64 * it;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) pre[it][cc] = (rr < nrows) ? entry(rho0 + rr, cq * 8 + cc) : 0.0;
+    }
+}
+template <class Entry>
+__device__ __forceinline__ void gb_combine(double *w, int xrow, const double (&pre)[GB_NPF][8], int rho0, int nrows, Entry entry) {
+    const int cq = threadIdx.x & 3, rq = threadIdx.x >> 2;
+    auto pass = [&](const double (&av)[8], int rr) {
+        double acc[GB_CB];
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const double *xp = w + (xrow + cq * 8 + cc) * GB_CB;
+#pragma unroll
+            for (int k = 0; k < GB_CB; ++k) acc[k] += av[cc] * xp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < GB_CB; ++k) acc[k] = gb_quad_sum(acc[k]);
+        if (rr < nrows) { // lane cq writes the right-hand sides 2 cq and 2 cq + 1 of its row
+            double *wr = w + (rho0 + rr) * GB_CB;
+#pragma unroll
+            for (int k = 0; k < GB_CB; ++k)
+                if ((k >> 1) == cq) wr[k] = wr[k] - acc[k];
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < GB_NPF; ++it)
+        if (64 * it < nrows) pass(pre[it], rq + 64 * it); // (uniform)
+    for (int base = 64 * GB_NPF; base < nrows; base += 64) { // a band wider than 256 rows outside the panel: the rest on demand
+        const int rr = rq + base;
+        double av[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) av[cc] = (rr < nrows) ? entry(rho0 + rr, cq * 8 + cc) : 0.0;
+        pass(av, rr);
     }
 }
 
@@ -420,46 +523,35 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
     GbLds L(lds_raw, R);
     const int tid = threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    GB_TICK(7);
     for (int k = 0; k < GB_CB; ++k)
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    // U(i0 + rho, j0 + c), rho < top: stored iff i >= j - kw
+    auto entry = [&](int rho, int c) -> double {
+        const int64_t i = i0 + rho, j = j0 + c;
+        return (c < ncol && i >= j - kw) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
+    };
+    double pre[GB_NPF][8];
+    gb_prefetch(pre, 0, top, entry);
+    const double warm = gb_warm(ab, ldab, n, j0 - GB_NB, 0, kl + ku + 1);
     __syncthreads();
-    if (tid < GB_CB) { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c); the 32 unknowns in registers
-        double xs[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] : 0.0;
-        gb_triangle<false, false, true>(xs, L.blk, ncol); // (blk is zero beyond ncol)
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c)
-            if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
+    GB_TICK(4);
+    { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c)   (blk is zero beyond ncol)
+        const int r = tid & 31, k = tid >> 5;
+        double x = (r < ncol) ? L.w[(top + r) * GB_CB + k] : 0.0;
+        x = gb_triangle_wave<false, false, true>(x, L.blk, ncol);
+        if (r < ncol) L.w[(top + r) * GB_CB + k] = x;
     }
     __syncthreads();
-    // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c.  A lane per (row, right-hand side): the 32 values of the panel
-    // for its right-hand side stay in registers (a lane per row with all 8 right-hand sides kept 256 of them live:
-    // 2.5 KB of spills per lane), the row's 32 entries of U are loaded first, then the arithmetic
-    {
-        const int k = tid & (GB_CB - 1), rl = tid / GB_CB;
-        double xp[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xp[c] = L.w[(top + c) * GB_CB + k];
-        for (int rho = rl; rho < top; rho += GB_T2 / GB_CB) {
-            const int64_t i = i0 + rho;
-            double av[GB_NB];
-#pragma unroll
-            for (int c = 0; c < GB_NB; ++c) {
-                const int64_t j = j0 + c;
-                av[c] = (c < ncol && i >= j - kw) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
-            }
-            double acc = L.w[rho * GB_CB + k];
-#pragma unroll
-            for (int c = 0; c < GB_NB; ++c) acc -= av[c] * xp[c];
-            L.w[rho * GB_CB + k] = acc;
-        }
-    }
+    GB_TICK(5);
+    gb_combine(L.w, top, pre, 0, top, entry); // rows above the panel: w[i] -= sum_c U(i, j0 + c) x_c
     __syncthreads();
+    GB_TICK(6);
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+    gb_keep(warm);
 }
 
 // L forward for a panel WITHOUT row swaps: rows j0 .. j0 + R - 1.
@@ -472,6 +564,7 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
     GbLds L(lds_raw, R);
     const int tid = threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.x) * GB_CB;
+    GB_TICK(3);
     for (int k = 0; k < GB_CB; ++k) {
         const int64_t t = t0 + k;
         for (int rho = tid; rho < R; rho += GB_T2) {
@@ -489,35 +582,26 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
         }
     }
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    // L(j0 + rho, j0 + c), rho >= ncol: stored iff rho <= c + kl
+    auto entry = [&](int rho, int c) -> double {
+        return (c < ncol && rho <= c + kl) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
+    };
+    double pre[GB_NPF][8];
+    gb_prefetch(pre, ncol, R - ncol, entry);
+    const double warm = BAND ? 0.0 : gb_warm(ab, ldab, n, j0 + GB_NB, kl + ku, kl + 1);
     __syncthreads();
-    if (tid < GB_CB) { // the triangle: x_c = b_c - sum_{c' < c} L(c, c') x_c'; the 32 unknowns in registers
-        const int lim = (ncol < R) ? ncol : R;
-        double xs[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] : 0.0;
-        gb_triangle<true, false, false>(xs, L.blk, ncol); // (blk is zero outside the panel)
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c)
-            if (c < lim) L.w[c * GB_CB + tid] = xs[c];
+    GB_TICK(0);
+    { // the triangle: x_c = b_c - sum_{c' < c} L(c, c') x_c'   (blk is zero outside the panel)
+        const int r = tid & 31, k = tid >> 5;
+        double x = (r < ncol && r < R) ? L.w[r * GB_CB + k] : 0.0;
+        x = gb_triangle_wave<true, false, false>(x, L.blk, ncol);
+        if (r < ncol && r < R) L.w[r * GB_CB + k] = x;
     }
     __syncthreads();
-    { // rows below the panel: a lane per (row, right-hand side), the panel's 32 values for the right-hand side in registers
-        const int k = tid & (GB_CB - 1), rl = tid / GB_CB;
-        double xp[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xp[c] = L.w[c * GB_CB + k];
-        for (int rho = ncol + rl; rho < R; rho += GB_T2 / GB_CB) {
-            double av[GB_NB];
-#pragma unroll
-            for (int c = 0; c < GB_NB; ++c)
-                av[c] = (c < ncol && rho <= c + kl) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
-            double acc = L.w[rho * GB_CB + k];
-#pragma unroll
-            for (int c = 0; c < GB_NB; ++c) acc -= av[c] * xp[c];
-            L.w[rho * GB_CB + k] = acc;
-        }
-    }
+    GB_TICK(1);
+    if (R > ncol) gb_combine(L.w, 0, pre, ncol, R - ncol, entry); // rows below the panel
     __syncthreads();
+    GB_TICK(2);
     for (int k = 0; k < GB_CB; ++k) {
         const int64_t t = t0 + k;
         if (t >= ntgt) continue;
@@ -531,9 +615,45 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
             }
         }
     }
+    if (!BAND) gb_keep(warm);
 }
 
-// U^T x = b, panel j0: x_j = (b_j - sum_{i < j} U(i, j) x_i) / U(j, j)
+// the dot products of the transposed sweeps: for each of the panel's columns c the sum over the rows outside the panel
+// of F(row, c) x_row, 8 lanes per column, each a strided share of the rows -- up to GB_DOT entries per lane loaded in one
+// round (a loop of four at a time was one round trip to HBM per four) -- partial sums to pa[c][g][k]
+constexpr int GB_DOT = 32;
+template <class Entry>
+__device__ __forceinline__ void gb_dots(const double *w, double *pa, int ncol, int rho_lo_common, Entry entry) {
+    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;
+    double acc[GB_CB];
+#pragma unroll
+    for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
+    if (c < ncol) {
+        int lo, hi; // rows [lo, hi) of the LDS window meet column c
+        entry.range(c, lo, hi);
+        for (int rb = lo + g; rb < hi; rb += 8 * GB_DOT) {
+            double av[GB_DOT];
+#pragma unroll
+            for (int q = 0; q < GB_DOT; ++q) {
+                const int rho = rb + 8 * q;
+                av[q] = (rho < hi) ? entry(rho, c) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < GB_DOT; ++q) {
+                const int rho = rb + 8 * q;
+                if (rho < hi) {
+#pragma unroll
+                    for (int k = 0; k < GB_CB; ++k) acc[k] += av[q] * w[rho * GB_CB + k];
+                }
+            }
+        }
+    }
+    (void)rho_lo_common;
+#pragma unroll
+    for (int k = 0; k < GB_CB; ++k) pa[(c * 8 + g) * GB_CB + k] = acc[k];
+}
+
+// U^T forward: x_j = (b_j - sum_{i < j} U(i, j) x_i) / U(j, j); rows i0 .. j0 + ncol - 1 in LDS
 __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t n,
                                                        int64_t j0, int ncol, int64_t ntgt, double *__restrict__ X, int64_t ldx) {
     extern __shared__ double lds_raw[];
@@ -546,36 +666,23 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    const double warm = gb_warm(ab, ldab, n, j0 + GB_NB, 0, kl + ku + 1);
     __syncthreads();
-    { // rows above the panel, all 32 columns at once: 8 lanes per column, each a strided share of the rows
-        const int c = tid >> 3, g = tid & 7;
-        double acc[GB_CB];
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
-        if (c < ncol) {
+    struct Above { // U(i0 + rho, j0 + c) for the rows above the panel: rho in [max(j - kw, i0) - i0, top)
+        const double *ab;
+        int ldab, kl, ku, kw, top;
+        int64_t i0, j0;
+        __device__ __forceinline__ void range(int c, int &lo, int &hi) const {
             const int64_t j = j0 + c;
-            const int64_t ilo = (j - kw > i0) ? j - kw : i0;
-            for (int64_t ib = ilo + g; ib < j0; ib += 32) { // four loads in flight per lane
-                double av[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t i = ib + 8 * q;
-                    av[q] = (i < j0) ? ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t i = ib + 8 * q;
-                    if (i < j0) {
-                        const int rho = static_cast<int>(i - i0);
-#pragma unroll
-                        for (int k = 0; k < GB_CB; ++k) acc[k] += av[q] * L.w[rho * GB_CB + k];
-                    }
-                }
-            }
+            lo = static_cast<int>(((j - kw > i0) ? j - kw : i0) - i0);
+            hi = top;
         }
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) L.pa[(c * 8 + g) * GB_CB + k] = acc[k];
-    }
+        __device__ __forceinline__ double operator()(int rho, int c) const {
+            const int64_t i = i0 + rho, j = j0 + c;
+            return ab[static_cast<size_t>(kl + ku + i - j) + static_cast<size_t>(j) * ldab];
+        }
+    } above{ab, ldab, kl, ku, kw, top, i0, j0};
+    gb_dots(L.w, L.pa, ncol, 0, above);
     __syncthreads();
     {
         const int c = tid >> 3, k = tid & 7;
@@ -584,19 +691,17 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
         L.part[c * GB_CB + k] = s;
     }
     __syncthreads();
-    if (tid < GB_CB) {
-        double xs[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < ncol) ? L.w[(top + c) * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
-        gb_triangle<true, true, true>(xs, L.blk, ncol);
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c)
-            if (c < ncol) L.w[(top + c) * GB_CB + tid] = xs[c];
+    { // the triangle on b - (what the rows above contribute)
+        const int r = tid & 31, k = tid >> 5;
+        double x = (r < ncol) ? L.w[(top + r) * GB_CB + k] - L.part[r * GB_CB + k] : 0.0;
+        x = gb_triangle_wave<true, true, true>(x, L.blk, ncol);
+        if (r < ncol) L.w[(top + r) * GB_CB + k] = x;
     }
     __syncthreads();
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = top + tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+    gb_keep(warm);
 }
 
 // L^T backward for a panel WITHOUT row swaps: x_j -= sum_{i > j} L(i, j) x_i
@@ -610,34 +715,21 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[j0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
+    const double warm = gb_warm(ab, ldab, n, j0 - GB_NB, kl + ku, kl + 1);
     __syncthreads();
-    { // rows below the panel, all columns at once
-        const int c = tid >> 3, g = tid & 7;
-        double acc[GB_CB];
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) acc[k] = 0.0;
-        if (c < ncol) {
-            const int hi = (c + kl < R - 1) ? c + kl : R - 1;
-            for (int rb = ncol + g; rb <= hi; rb += 32) {
-                double av[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rho = rb + 8 * q;
-                    av[q] = (rho <= hi) ? ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rho = rb + 8 * q;
-                    if (rho <= hi) {
-#pragma unroll
-                        for (int k = 0; k < GB_CB; ++k) acc[k] += av[q] * L.w[rho * GB_CB + k];
-                    }
-                }
-            }
+    struct Below { // L(j0 + rho, j0 + c) for the rows below the panel: rho in [ncol, min(c + kl, R - 1)]
+        const double *ab;
+        int ldab, kl, ku, ncol, R;
+        int64_t j0;
+        __device__ __forceinline__ void range(int c, int &lo, int &hi) const {
+            lo = ncol;
+            hi = ((c + kl < R - 1) ? c + kl : R - 1) + 1;
         }
-#pragma unroll
-        for (int k = 0; k < GB_CB; ++k) L.pa[(c * 8 + g) * GB_CB + k] = acc[k];
-    }
+        __device__ __forceinline__ double operator()(int rho, int c) const {
+            return ab[static_cast<size_t>(kl + ku + rho - c) + static_cast<size_t>(j0 + c) * ldab];
+        }
+    } below{ab, ldab, kl, ku, ncol, R, j0};
+    gb_dots(L.w, L.pa, ncol, 0, below);
     __syncthreads();
     {
         const int c = tid >> 3, k = tid & 7;
@@ -646,21 +738,18 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
         L.part[c * GB_CB + k] = s;
     }
     __syncthreads();
-    if (tid < GB_CB) {
-        const int lim = (ncol < R) ? ncol : R;
-        double xs[GB_NB];
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c) xs[c] = (c < lim) ? L.w[c * GB_CB + tid] - L.part[c * GB_CB + tid] : 0.0;
-        gb_triangle<false, true, false>(xs, L.blk, ncol); // (blk is zero outside the panel)
-#pragma unroll
-        for (int c = 0; c < GB_NB; ++c)
-            if (c < lim) L.w[c * GB_CB + tid] = xs[c];
+    const int lim = (ncol < R) ? ncol : R;
+    { // the triangle   (blk is zero outside the panel)
+        const int r = tid & 31, k = tid >> 5;
+        double x = (r < lim) ? L.w[r * GB_CB + k] - L.part[r * GB_CB + k] : 0.0;
+        x = gb_triangle_wave<false, true, false>(x, L.blk, ncol);
+        if (r < lim) L.w[r * GB_CB + k] = x;
     }
     __syncthreads();
-    const int lim = (ncol < R) ? ncol : R;
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = tid; rho < lim; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
+    gb_keep(warm);
 }
 
 // ------------------------------------------------------------------------------------------- launch wrappers
@@ -684,6 +773,9 @@ __global__ __launch_bounds__(GB_T2) void k_gb_solve_loop(double *__restrict__ ab
                                                          const int32_t *__restrict__ ipiv, const uint8_t *__restrict__ swaps,
                                                          int64_t ntgt, double *__restrict__ X, int64_t ldx, int trans, int stepwise) {
     const int64_t npanel = (n + GB_NB - 1) / GB_NB;
+#ifdef SX_GB_TICKS
+    const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
+#endif
     if (!trans) {
         for (int64_t p = 0; p < npanel; ++p) {
             const int64_t j0 = p * GB_NB;
@@ -713,6 +805,12 @@ __global__ __launch_bounds__(GB_T2) void k_gb_solve_loop(double *__restrict__ ab
             __syncthreads();
         }
     }
+#ifdef SX_GB_TICKS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_gb_t[8] = clock64() - c0_;
+        g_gb_t[9] = wall_clock64() - w0_;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- sparse right-hand sides
@@ -948,6 +1046,20 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     hipLaunchKernelGGL(k_gb_solve_loop, dim3(grid), dim3(GB_T2), gb_lds_bytes(kl + ku + GB_NB), s, h->ab, h->ldab, kl, ku, n, h->ipiv,
                        h->d_swaps, nrhs, X, ldx, trans ? 1 : 0, slow ? 1 : 0);
     SX_HIP(hipGetLastError());
+#ifdef SX_GB_TICKS
+    {
+        unsigned long long t[16];
+        SX_HIP(hipStreamSynchronize(s));
+        SX_HIP(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gb_t), sizeof(t)));
+        const double np = static_cast<double>((n + GB_NB - 1) / GB_NB) * 100.0; // ticks of 10 ns -> us per panel
+        fprintf(stderr, "[sx_bandlu] us per panel (cumulative over the calls so far / panels of this one): L loads %.2f triangle %.2f combine %.2f "
+                        "stores+gap %.2f | U loads %.2f triangle %.2f combine %.2f stores+gap %.2f\n",
+                t[0] / np, t[1] / np, t[2] / np, t[3] / np, t[4] / np, t[5] / np, t[6] / np, t[7] / np);
+        fprintf(stderr, "[sx_bandlu] shader clock during the solve: %.0f MHz\n", t[9] ? 100.0 * static_cast<double>(t[8]) / static_cast<double>(t[9]) : 0.0);
+        unsigned long long z[16] = {0};
+        SX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gb_t), z, sizeof(z)));
+    }
+#endif
     return SX_OK;
 }
 
