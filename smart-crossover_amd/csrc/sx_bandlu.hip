@@ -406,22 +406,6 @@ __device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int
     }
 }
 
-// The NEXT panel's part of the factor into L2 while this one is worked on: one load per 128-byte line of the entries
-// [off0, off0 + cnt) (band storage) of the columns jn0 .. jn0 + 31.  The sum only keeps the loads alive: the caller
-// hands it to gb_keep at the END of its step, so that nothing waits for these loads before the step's own work is done.
-__device__ __forceinline__ double gb_warm(const double *__restrict__ ab, int ldab, int64_t n, int64_t jn0, int off0, int cnt) {
-    double acc = 0.0;
-    const int lines = (cnt + 15) / 16;
-    for (int e = threadIdx.x; e < GB_NB * lines; e += GB_T2) {
-        const int c = e / lines, l = e - c * lines;
-        const int64_t j = jn0 + c;
-        const int o = (l * 16 < cnt - 1) ? l * 16 : cnt - 1;
-        if (j >= 0 && j < n) acc += ab[static_cast<size_t>(j) * ldab + off0 + o];
-    }
-    return acc;
-}
-__device__ __forceinline__ void gb_keep(double v) { asm volatile("" ::"v"(v)); }
-
 // The 32 x 32 triangle of a panel, a lane per (unknown r, right-hand side): wave w holds the right-hand sides 2 w and
 // 2 w + 1 in its two halves.  Column by column: x_c is final when its turn comes (after the multiplication by the
 // reciprocal of the diagonal with DIAG) and goes to the 32 lanes of its right-hand side through v_readlane -- no LDS
@@ -534,7 +518,6 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
     };
     double pre[GB_NPF][8];
     gb_prefetch(pre, 0, top, entry);
-    const double warm = gb_warm(ab, ldab, n, j0 - GB_NB, 0, kl + ku + 1);
     __syncthreads();
     GB_TICK(4);
     { // the triangle: x_c = (b_c - sum_{c'' > c} U(c, c'') x_c'') / U(c, c)   (blk is zero beyond ncol)
@@ -551,7 +534,6 @@ __device__ __forceinline__ void gb_usolve2_body(const double *__restrict__ ab, i
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
-    gb_keep(warm);
 }
 
 // L forward for a panel WITHOUT row swaps: rows j0 .. j0 + R - 1.
@@ -588,7 +570,6 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
     };
     double pre[GB_NPF][8];
     gb_prefetch(pre, ncol, R - ncol, entry);
-    const double warm = BAND ? 0.0 : gb_warm(ab, ldab, n, j0 + GB_NB, kl + ku, kl + 1);
     __syncthreads();
     GB_TICK(0);
     { // the triangle: x_c = b_c - sum_{c' < c} L(c, c') x_c'   (blk is zero outside the panel)
@@ -615,7 +596,6 @@ __device__ __forceinline__ void gb_lsolve2_body(double *__restrict__ ab, int lda
             }
         }
     }
-    if (!BAND) gb_keep(warm);
 }
 
 // the dot products of the transposed sweeps: for each of the panel's columns c the sum over the rows outside the panel
@@ -666,7 +646,6 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[i0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
-    const double warm = gb_warm(ab, ldab, n, j0 + GB_NB, 0, kl + ku + 1);
     __syncthreads();
     struct Above { // U(i0 + rho, j0 + c) for the rows above the panel: rho in [max(j - kw, i0) - i0, top)
         const double *ab;
@@ -701,7 +680,6 @@ __device__ __forceinline__ void gb_utsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = top + tid; rho < R; rho += GB_T2) X[i0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
-    gb_keep(warm);
 }
 
 // L^T backward for a panel WITHOUT row swaps: x_j -= sum_{i > j} L(i, j) x_i
@@ -715,7 +693,6 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         for (int rho = tid; rho < R; rho += GB_T2) L.w[rho * GB_CB + k] = (t0 + k < ntgt) ? X[j0 + rho + (t0 + k) * ldx] : 0.0;
     gb_load_block(ab, ldab, kl, ku, j0, ncol, L.blk);
-    const double warm = gb_warm(ab, ldab, n, j0 - GB_NB, kl + ku, kl + 1);
     __syncthreads();
     struct Below { // L(j0 + rho, j0 + c) for the rows below the panel: rho in [ncol, min(c + kl, R - 1)]
         const double *ab;
@@ -749,7 +726,6 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
     for (int k = 0; k < GB_CB; ++k)
         if (t0 + k < ntgt)
             for (int rho = tid; rho < lim; rho += GB_T2) X[j0 + rho + (t0 + k) * ldx] = L.w[rho * GB_CB + k];
-    gb_keep(warm);
 }
 
 // ------------------------------------------------------------------------------------------- launch wrappers
