@@ -168,13 +168,32 @@ __global__ __launch_bounds__(TB_WG) void k_tb_infeas(int64_t m, const double *__
     }
 }
 
-__global__ __launch_bounds__(TB_WG) void k_tb_phase(int nblk, const double *__restrict__ part, TbState *st) {
+__global__ __launch_bounds__(TB_WG) void k_tb_phase(int nblk, const double *__restrict__ part, TbState *st, int32_t *__restrict__ infoff) {
     __shared__ double sm[4];
+    __shared__ int sc[TB_WG];
     if (st->status != 0) return;
+    // thread t owns the blocks [t c, (t + 1) c): their counts, then an exclusive scan -> infoff[block] = infeasible
+    // positions before it (k_tb_inflist writes the list of positions in ascending order from these)
+    const int chunk = (nblk + TB_WG - 1) / TB_WG;
+    const int k0 = threadIdx.x * chunk, k1 = (k0 + chunk < nblk) ? k0 + chunk : nblk;
     double cnt = 0.0, sum = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += TB_WG) { // (counts are small integers: any order gives the same sum)
+    for (int k = k0; k < k1; ++k) { // (counts are small integers: any order gives the same sum)
         cnt += part[2 * k];
         sum += part[2 * k + 1];
+    }
+    const int mine = static_cast<int>(cnt);
+    sc[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < TB_WG; o <<= 1) {
+        const int v = (threadIdx.x >= o) ? sc[threadIdx.x - o] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sc[threadIdx.x] - mine;
+    for (int k = k0; k < k1; ++k) {
+        infoff[k] = run;
+        run += static_cast<int>(part[2 * k]);
     }
     cnt = tb_block_sum(cnt, sm);
     sum = tb_block_sum(sum, sm);
@@ -185,11 +204,32 @@ __global__ __launch_bounds__(TB_WG) void k_tb_phase(int nblk, const double *__re
     }
 }
 
+// phase 1: the infeasible positions in ascending order (at most TB_INFLIST of them; more: the pricing kernels read
+// the columns whole).  A workgroup per block of 256 positions that holds one: ordered compaction by ballots.
+constexpr int TB_INFLIST = 4096;
+__global__ __launch_bounds__(TB_WG) void k_tb_inflist(int64_t m, const double *__restrict__ g, const double *__restrict__ part,
+                                                      const int32_t *__restrict__ infoff, const TbState *__restrict__ st,
+                                                      int32_t *__restrict__ list) {
+    __shared__ int wsum[TB_WG / 64];
+    if (st->status != 0 || st->phase != 1 || st->n_inf > TB_INFLIST) return;
+    if (part[2 * blockIdx.x] <= 0.0) return;
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
+    const bool hit = p < m && g[p] != 0.0;
+    const unsigned long long bal = __ballot(hit);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (hit) list[infoff[blockIdx.x] + before + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<int32_t>(p);
+}
+
 // phase 1 only: d1[j] = - g^T (current column j) = -( g^T base_j - sum_{s >= s0[j]} (g^T u_s) v_s[j] ).  Few basic
-// variables are infeasible behind a first-order point, so g^T T[:, j] visits only the blocks of 256 positions that
-// hold one (counts from k_tb_infeas), a lane per block; with many of them it reads the column whole, coalesced.
+// variables are infeasible behind a first-order point, so g^T T[:, j] gathers the listed positions only (k_tb_inflist:
+// ~200 of 1e6 at config-5 size -- scanning the 256-position blocks that hold one cost 1.3 ms per iteration there);
+// with more than TB_INFLIST of them it reads the column whole, coalesced.
 __global__ __launch_bounds__(TB_WG) void k_tb_gu(int64_t m, int nblk, const double *__restrict__ eta, const double *__restrict__ g,
-                                                 const double *__restrict__ part, const TbState *__restrict__ st, TbPend P,
+                                                 const int32_t *__restrict__ list, const TbState *__restrict__ st, TbPend P,
                                                  double *__restrict__ gu) {
     __shared__ double sm[4];
     if (st->status != 0 || st->phase != 1) return;
@@ -198,15 +238,11 @@ __global__ __launch_bounds__(TB_WG) void k_tb_gu(int64_t m, int nblk, const doub
     const double *al = eta + static_cast<size_t>(st->n_eta - st->n_pend + sidx) * m;
     const int r = P.pr[sidx];
     double acc = 0.0;
-    if (st->n_inf <= 4096) {
-        for (int k = threadIdx.x; k < nblk; k += TB_WG)
-            if (part[2 * k] > 0.0) {
-                const int64_t p0 = static_cast<int64_t>(k) * TB_WG, p1 = (p0 + TB_WG < m) ? p0 + TB_WG : m;
-                for (int64_t p = p0; p < p1; ++p) {
-                    const double gp = g[p];
-                    if (gp != 0.0) acc += gp * (al[p] - (p == r ? 1.0 : 0.0));
-                }
-            }
+    if (st->n_inf <= TB_INFLIST) {
+        for (int i = threadIdx.x; i < st->n_inf; i += TB_WG) {
+            const int p = list[i];
+            acc += g[p] * (al[p] - (p == r ? 1.0 : 0.0));
+        }
     } else {
         for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
             const double gp = g[p];
@@ -218,7 +254,7 @@ __global__ __launch_bounds__(TB_WG) void k_tb_gu(int64_t m, int nblk, const doub
 }
 
 __global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const double *__restrict__ T, const double *__restrict__ g,
-                                                     const double *__restrict__ part, const TbState *__restrict__ st, TbPend P,
+                                                     const int32_t *__restrict__ list, const TbState *__restrict__ st, TbPend P,
                                                      const double *__restrict__ gu, double *__restrict__ d1) {
     __shared__ double sm[4];
     if (st->status != 0 || st->phase != 1) return;
@@ -229,15 +265,11 @@ __global__ __launch_bounds__(TB_WG) void k_tb_price1(int64_t m, int nblk, const 
         if (threadIdx.x == 0) acc = g[sb];
     } else {
         const double *col = T + static_cast<size_t>(s) * m;
-        if (st->n_inf <= 4096) {
-            for (int k = threadIdx.x; k < nblk; k += TB_WG)
-                if (part[2 * k] > 0.0) {
-                    const int64_t p0 = static_cast<int64_t>(k) * TB_WG, p1 = (p0 + TB_WG < m) ? p0 + TB_WG : m;
-                    for (int64_t p = p0; p < p1; ++p) {
-                        const double gp = g[p];
-                        if (gp != 0.0) acc += gp * col[p];
-                    }
-                }
+        if (st->n_inf <= TB_INFLIST) {
+            for (int i = threadIdx.x; i < st->n_inf; i += TB_WG) {
+                const int p = list[i];
+                acc += g[p] * col[p];
+            }
         } else {
             for (int64_t p = threadIdx.x; p < m; p += TB_WG) {
                 const double gp = g[p];
@@ -569,26 +601,31 @@ __global__ __launch_bounds__(TB_WG) void k_tb_update(int64_t m, double *__restri
 }
 
 // One pass over the tableau for a whole batch: T[p, j] = base - sum_{s >= s0[j]} u_s[p] v_s[j].  A lane owns a
-// position (its u_s in registers, 64 at most), a workgroup 32 slots (their v_s in LDS).
+// position (its u_s in registers, 64 at most), a workgroup TB_FJ slots (their v_s in LDS).
 __global__ void k_tb_fold_begin(TbState *st, int slack) {
     st->folding = (st->n_pend > 0 && (st->status != 0 || st->n_pend + slack > TB_K)) ? 1 : 0;
 }
+constexpr int TB_FJ = 64; // slots per workgroup of the fold: the batch's u_s[p] are read once per TB_FJ columns
 __global__ __launch_bounds__(TB_WG) void k_tb_fold(int64_t m, int64_t nJ, double *__restrict__ T, const double *__restrict__ eta,
                                                    const TbState *__restrict__ st, TbPend P) {
-    __shared__ double vs[TB_K][33];
-    __shared__ int ss0[32], ssb[32];
+    __shared__ double vs[TB_K][TB_FJ + 1];
+    __shared__ int ss0[TB_FJ], ssb[TB_FJ], snz[TB_FJ];
     if (!st->folding) return;
     const int np = st->n_pend;
     const long long e0 = st->n_eta - np;
-    const int64_t j0 = static_cast<int64_t>(blockIdx.y) * 32;
-    const int nj = static_cast<int>((nJ - j0 < 32) ? nJ - j0 : 32);
-    for (int e = threadIdx.x; e < TB_K * 32; e += TB_WG) {
-        const int sidx = e / 32, jj = e % 32;
-        vs[sidx][jj] = (sidx < np && jj < nj) ? P.vbuf[static_cast<size_t>(sidx) * P.ldv + j0 + jj] : 0.0;
-    }
-    if (threadIdx.x < 32) {
+    const int64_t j0 = static_cast<int64_t>(blockIdx.y) * TB_FJ;
+    const int nj = static_cast<int>((nJ - j0 < TB_FJ) ? nJ - j0 : TB_FJ);
+    if (threadIdx.x < TB_FJ) {
         ss0[threadIdx.x] = threadIdx.x < nj ? P.s0[j0 + threadIdx.x] : np;
         ssb[threadIdx.x] = threadIdx.x < nj ? P.sbase[j0 + threadIdx.x] : -1;
+        snz[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TB_K * TB_FJ; e += TB_WG) {
+        const int sidx = e / TB_FJ, jj = e % TB_FJ;
+        const double v = (sidx < np && jj < nj) ? P.vbuf[static_cast<size_t>(sidx) * P.ldv + j0 + jj] : 0.0;
+        vs[sidx][jj] = v;
+        if (v != 0.0 && sidx >= ss0[jj]) snz[jj] = 1; // (every writer stores 1)
     }
     __syncthreads();
     for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG) {
@@ -603,13 +640,14 @@ __global__ __launch_bounds__(TB_WG) void k_tb_fold(int64_t m, int64_t nJ, double
         }
         for (int jj = 0; jj < nj; ++jj) {
             const int sb = ssb[jj];
-            if (!any && sb < 0) continue; // the row saw none of the batch's pivots and the slot keeps its column
+            // the row saw none of the batch's pivots, or the column none of its pivot rows: the slot keeps its entry
+            if ((!any || !snz[jj]) && sb < 0) continue;
             double *t = T + static_cast<size_t>(j0 + jj) * m + p;
             double acc = sb < 0 ? *t : (p == sb ? 1.0 : 0.0);
             const int first = ss0[jj];
 #pragma unroll
             for (int sidx = 0; sidx < TB_K; ++sidx)
-                if (sidx >= first && sidx < np) acc -= u[sidx] * vs[sidx][jj];
+                if (sidx >= first && sidx < np) acc = __builtin_fma(-u[sidx], vs[sidx][jj], acc); // (fused: this pass is arithmetic bound)
             *t = fabs(acc) < TB_DROP ? 0.0 : acc;
         }
     }
@@ -1027,7 +1065,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
            *d_part = nullptr, *d_infpart = nullptr, *d_vec = nullptr;
     int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr, *d_blist = nullptr;
-    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr, *d_elist = nullptr;
+    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr, *d_elist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr;
     double *d_ebG = nullptr, *d_ebM = nullptr, *d_ebS = nullptr;
     double *d_vbuf = nullptr, *d_gu = nullptr;
     TbPart *d_rpart = nullptr;
@@ -1043,6 +1081,8 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_part));
     SX_TRY(dev.get(static_cast<size_t>(nblk), &d_blist));
     SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_infpart));
+    SX_TRY(dev.get(static_cast<size_t>(nblk), &d_infoff));
+    SX_TRY(dev.get(static_cast<size_t>(TB_INFLIST), &d_inflist));
     SX_TRY(dev.get(static_cast<size_t>(nblk), &d_rpart));
     SX_TRY(dev.get(1, &d_st));
 
@@ -1402,9 +1442,10 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         // ---------------------------------------------------------------- the simplex on the tracked columns
         auto one_pivot = [&]() {
             hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
-            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st);
-            hipLaunchKernelGGL(k_tb_gu, dim3(TB_K), dim3(TB_WG), 0, s, m, nblk, d_eta, d_g, d_infpart, d_st, pend, d_gu);
-            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_infpart, d_st, pend, d_gu, d_d1);
+            hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st, d_infoff);
+            hipLaunchKernelGGL(k_tb_inflist, dim3(nblk), dim3(TB_WG), 0, s, m, d_g, d_infpart, d_infoff, d_st, d_inflist);
+            hipLaunchKernelGGL(k_tb_gu, dim3(TB_K), dim3(TB_WG), 0, s, m, nblk, d_eta, d_g, d_inflist, d_st, pend, d_gu);
+            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_inflist, d_st, pend, d_gu, d_d1);
             hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
             hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part, pend);
             hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st, d_blist);
@@ -1417,7 +1458,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         };
         auto fold = [&]() { // applies the pending batch when it is nearly full, or when the run has stopped
             hipLaunchKernelGGL(k_tb_fold_begin, dim3(1), dim3(1), 0, s, d_st, 16);
-            hipLaunchKernelGGL(k_tb_fold, dim3(static_cast<unsigned>(std::min(nblk, 128)), static_cast<unsigned>((nJ + 31) / 32)), dim3(TB_WG), 0, s,
+            hipLaunchKernelGGL(k_tb_fold, dim3(static_cast<unsigned>(std::min(nblk, 128)), static_cast<unsigned>((nJ + TB_FJ - 1) / TB_FJ)), dim3(TB_WG), 0, s,
                                m, nJ, d_T, d_eta, d_st, pend);
             hipLaunchKernelGGL(k_tb_fold_end, dim3(gridof(nJ)), dim3(TB_WG), 0, s, nJ, d_st, d_s0, d_sbase);
             hipLaunchKernelGGL(k_tb_fold_done, dim3(1), dim3(1), 0, s, d_st);
@@ -1437,7 +1478,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 }
             } else { // nothing tracked: only the state of the basic variables decides the phase
                 hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
-                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st);
+                hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st, d_infoff);
                 SX_HIP(hipMemcpyAsync(&hst, d_st, sizeof(hst), hipMemcpyDeviceToHost, s));
                 SX_HIP(hipStreamSynchronize(s));
                 hst.status = 1;
