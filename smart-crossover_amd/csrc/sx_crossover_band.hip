@@ -623,9 +623,12 @@ __global__ __launch_bounds__(TB_WG) void k_tb_fold(int64_t m, int64_t nJ, double
     __syncthreads();
     for (int e = threadIdx.x; e < TB_K * TB_FJ; e += TB_WG) {
         const int sidx = e / TB_FJ, jj = e % TB_FJ;
-        const double v = (sidx < np && jj < nj) ? P.vbuf[static_cast<size_t>(sidx) * P.ldv + j0 + jj] : 0.0;
+        // zero where the pivot does not apply to the slot (before its s0, beyond the batch): the inner loop below is 64
+        // multiply-adds without a test -- with `if (sidx >= first && sidx < np)` around each, the uniform branches cost five
+        // times the arithmetic (105 ms per pass at config-5 size)
+        const double v = (sidx < np && jj < nj && sidx >= ss0[jj]) ? P.vbuf[static_cast<size_t>(sidx) * P.ldv + j0 + jj] : 0.0;
         vs[sidx][jj] = v;
-        if (v != 0.0 && sidx >= ss0[jj]) snz[jj] = 1; // (every writer stores 1)
+        if (v != 0.0) snz[jj] = 1; // (every writer stores 1)
     }
     __syncthreads();
     for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG) {
@@ -644,10 +647,8 @@ __global__ __launch_bounds__(TB_WG) void k_tb_fold(int64_t m, int64_t nJ, double
             if ((!any || !snz[jj]) && sb < 0) continue;
             double *t = T + static_cast<size_t>(j0 + jj) * m + p;
             double acc = sb < 0 ? *t : (p == sb ? 1.0 : 0.0);
-            const int first = ss0[jj];
 #pragma unroll
-            for (int sidx = 0; sidx < TB_K; ++sidx)
-                if (sidx >= first && sidx < np) acc = __builtin_fma(-u[sidx], vs[sidx][jj], acc); // (fused: this pass is arithmetic bound)
+            for (int sidx = 0; sidx < TB_K; ++sidx) acc = __builtin_fma(-u[sidx], vs[sidx][jj], acc); // (u is zero beyond the batch)
             *t = fabs(acc) < TB_DROP ? 0.0 : acc;
         }
     }
