@@ -208,3 +208,43 @@ def test_shuffled_rows_fall_back_into_a_band(ctx, monkeypatch):
     # same LP up to the permutation (the perturbation xi is drawn per position, so only the original objectives agree)
     x0, x1 = mgr0.get_orix(o0.x), mgr1.get_orix(o1.x)
     assert float(inst.c @ x0) == pytest.approx(float(shuf.c @ x1), rel=1e-7)
+
+
+def test_a_full_eta_file_restarts_with_a_fresh_factorisation(ctx, monkeypatch):
+    """SX_BAND_EPOCH = 40: the eta file holds 40 basis changes, so the run has to stop, match and factor the current
+    basis afresh and go on (several epochs); same optimum as with the default capacity."""
+    inst = small_band_lp()
+    lt = inst.sense == "<"
+    want = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, inst.x)
+    assert int(want[0].status) == 0 and int(want[0].iters) > 100
+    monkeypatch.setenv("SX_BAND_EPOCH", "40")
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, inst.x)
+    assert int(res.status) == 0
+    assert float(inst.c @ x) == pytest.approx(float(inst.c @ want[1]), rel=1e-9, abs=1e-9)
+    s_p = inst.b - inst.A @ x
+    assert np.abs(s_p[~lt]).max() < 1e-6 and s_p[lt].min() > -1e-6
+    assert int((vb == 0).sum() + (cb == 0).sum()) == inst.A.shape[0]
+
+
+@pytest.mark.parametrize("seed,scale", [(4, 0.3), (5, 1.0)])
+def test_another_cost_brings_columns_in_by_pricing(ctx, seed, scale):
+    """The interior point of the original LP as the start for a DIFFERENT cost vector: the columns the optimum needs are
+    non-basic at a bound at the start, so pricing over all columns has to bring them into the tableau after the first
+    basis changes (duals through the eta file, new columns through it 64 etas at a time).  Optimum = HiGHS'."""
+    inst = small_band_lp()
+    lt = inst.sense == "<"
+    rng = np.random.default_rng(seed)
+    c = inst.c + scale * rng.standard_normal(inst.c.size)
+    u = np.where(np.isinf(inst.u), 30.0, inst.u)            # (bounded: any cost has an optimum)
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, c, inst.l, u, lt, np.clip(inst.x, inst.l, u))
+    assert int(res.status) == 0
+    assert int(res.phase1_iters) > 0        # (the field counts the columns that pricing brought into the tableau)
+    ref = linprog(c, A_ub=inst.A[lt], b_ub=inst.b[lt], A_eq=inst.A[~lt], b_eq=inst.b[~lt], bounds=list(zip(inst.l, u)), method="highs")
+    assert ref.status == 0
+    assert float(c @ x) == pytest.approx(ref.fun, rel=1e-8, abs=1e-8)
+    s_p = inst.b - inst.A @ x
+    assert np.abs(s_p[~lt]).max() < 1e-6 and s_p[lt].min() > -1e-6
+    assert np.all(x >= inst.l - 1e-9) and np.all(x <= u + 1e-9)
+    rc = c - inst.A.T @ y
+    assert np.all(rc[vb == -1] >= -1e-6) and np.all(rc[vb == -2] <= 1e-6) and np.abs(rc[vb == 0]).max() < 1e-6
+    assert int((vb == 0).sum() + (cb == 0).sum()) == inst.A.shape[0]
