@@ -39,6 +39,11 @@ struct sx_bandlu {
     size_t flags_cap = 0;
     bool factored = false;
     std::vector<uint8_t> panel_swaps; // [panels] 1: the panel's factorisation swapped rows (host copy)
+    // partitioned sweeps (k_gbp_*): per sweep kind the responses R of every block to its incoming rows; work buffers
+    int part_state = 0; // 0: not tried yet, 1: ready, -1: not available (too few panels, or no memory): sequential sweeps
+    int part_LBp = 0, part_P = 0;
+    double *part_R[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *part_buf = nullptr, *part_delta = nullptr;
 };
 
 namespace {
@@ -883,6 +888,184 @@ __global__ __launch_bounds__(GB_T2) void k_gb_solve_sparse(double *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------- partitioned sweeps
+// A sweep of a solve is ONE chain of n / 32 panel steps on ONE workgroup (85-95 ms at 1e5 rows, whatever the number of
+// right-hand sides).  A panel reaches w rows beyond itself (w = kl for the sweeps with L, kl + ku for those with U), so
+// the panels are cut into P blocks of >= w rows: block i's result is a linear function of its own right-hand side and
+// of w "incoming" rows that the block before it (in sweep order) finishes,
+//      result_i = sweep_i(own rows, assumed incoming rows) + R_i (true incoming - assumed incoming),
+// with R_i = the block's sweep applied to the w unit vectors of its incoming rows -- a property of the factors, computed
+// once per handle.  A solve then is  (1) every block's sweep on a private copy of its rows, all blocks at once;
+// (2) a chain over the blocks of w x w products for the true incoming rows (true outgoing_i = outgoing_i + M_i delta_i,
+// M_i = the outgoing rows of R_i); (3) result += R_i delta_i, all blocks at once.  P = 64 .. 128: ~50 panel steps + P small
+// products instead of n / 32 steps.  Incoming / outgoing rows by kind (s, e = the block's first row and the one after
+// its last; the buffer holds the rows [lo, hi)):
+//   0  L forward    buffer [s, e + w)   in = first w own rows (assumed: b)        out = the w rows after e (they ARE the next block's in)
+//   1  U backward   buffer [s - w, e)   in = last w own rows (assumed: b)         out = the w rows before s
+//   2  U^T forward  buffer [s - w, e)   in = the w rows before s (assumed: 0)     out = last w own rows
+//   3  L^T backward buffer [s, e + w)   in = the w rows after e (assumed: 0)      out = first w own rows; the row swaps of the
+//                                       block's columns reach into its in rows: their final values are this block's (k_gbp_fix)
+struct GbPart {
+    int kind, w, LBp, P;
+    int64_t n, npanel;
+    int ld_small, ld_last; // rows of a block's buffer (all blocks but the last / the last)
+    __host__ __device__ int64_t p0(int i) const { return static_cast<int64_t>(i) * LBp; }
+    __host__ __device__ int64_t p1(int i) const { return i == P - 1 ? npanel : static_cast<int64_t>(i + 1) * LBp; }
+    __host__ __device__ int64_t s(int i) const { return p0(i) * GB_NB; }
+    __host__ __device__ int64_t e(int i) const { return i == P - 1 ? n : p1(i) * GB_NB; }
+    __host__ __device__ int64_t lo(int i) const { return (kind == 0 || kind == 3) ? s(i) : (s(i) - w > 0 ? s(i) - w : 0); }
+    __host__ __device__ int64_t hi(int i) const { return (kind == 0 || kind == 3) ? (e(i) + w < n ? e(i) + w : n) : e(i); }
+    __host__ __device__ int ld(int i) const { return i == P - 1 ? ld_last : ld_small; }
+    __host__ __device__ size_t rows_before(int i) const { return static_cast<size_t>(i) * ld_small; } // buffer rows of the blocks before i
+    __host__ __device__ size_t rows_total() const { return static_cast<size_t>(P - 1) * ld_small + ld_last; }
+    __host__ __device__ bool forward() const { return kind == 0 || kind == 2; }
+    // global rows of the incoming / outgoing rows (w of them; a block at the start of the sweep has no incoming ones)
+    __host__ __device__ int64_t in0(int i) const { return kind == 0 ? s(i) : kind == 1 ? e(i) - w : kind == 2 ? s(i) - w : e(i); }
+    __host__ __device__ int64_t out0(int i) const { return kind == 0 ? e(i) : kind == 1 ? s(i) - w : kind == 2 ? e(i) - w : s(i); }
+    __host__ __device__ bool first_in_order(int i) const { return forward() ? i == 0 : i == P - 1; }
+    __host__ __device__ bool last_in_order(int i) const { return forward() ? i == P - 1 : i == 0; }
+};
+
+// private copies: buf_i[t][r] = X[lo_i + r, t]; rows outside the block's own rows are zero for the pulling kinds (2, 3)
+__global__ __launch_bounds__(256) void k_gbp_gather(GbPart D, int ncols, const double *__restrict__ X, int64_t ldx, double *__restrict__ bufs) {
+    const int i = blockIdx.y;
+    const int ld = D.ld(i);
+    const int64_t lo = D.lo(i), hi = D.hi(i), s = D.s(i), e = D.e(i);
+    double *b = bufs + D.rows_before(i) * ncols;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; q < static_cast<int64_t>(ld) * ncols; q += static_cast<int64_t>(gridDim.x) * 256) {
+        const int t = static_cast<int>(q / ld);
+        const int64_t g = lo + (q - static_cast<int64_t>(t) * ld);
+        double v = 0.0;
+        if (g < hi && (D.kind < 2 || (g >= s && g < e))) v = X[g + t * ldx];
+        b[q] = v;
+    }
+}
+// the w unit vectors of block i's incoming rows as its right-hand sides (-> R_i after the sweep)
+__global__ __launch_bounds__(256) void k_gbp_unit(GbPart D, double *__restrict__ R) {
+    const int i = blockIdx.y;
+    const int ld = D.ld(i);
+    double *b = R + D.rows_before(i) * D.w;
+    const int64_t lo = D.lo(i), in0 = D.in0(i);
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; q < static_cast<int64_t>(ld) * D.w; q += static_cast<int64_t>(gridDim.x) * 256) {
+        const int c = static_cast<int>(q / ld);
+        const int64_t g = lo + (q - static_cast<int64_t>(c) * ld);
+        b[q] = (!D.first_in_order(i) && g == in0 + c) ? 1.0 : 0.0;
+    }
+}
+// block blockIdx.y's panels on its private rows; right-hand sides 8 per workgroup (blockIdx.x), as in k_gb_solve_loop
+__global__ __launch_bounds__(GB_T2) void k_gbp_sweep(double *__restrict__ ab, int ldab, int kl, int ku, const int32_t *__restrict__ ipiv,
+                                                     const uint8_t *__restrict__ swaps, GbPart D, int ncols, double *__restrict__ bufs) {
+    const int i = blockIdx.y;
+    const int64_t n = D.n;
+    double *X = bufs + D.rows_before(i) * ncols - D.lo(i); // (global row numbers address the private copy)
+    const int64_t ldx = D.ld(i);
+    const int64_t p0 = D.p0(i), p1 = D.p1(i);
+    if (D.forward()) {
+        for (int64_t p = p0; p < p1; ++p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            if (D.kind == 0) {
+                if (swaps[p]) gb_apply_body<false>(ab, ldab, kl, ku, n, j0, ncol, ipiv, 0, ncols, X, ldx);
+                else gb_lsolve2_body<false>(ab, ldab, kl, ku, n, j0, ncol, 0, ncols, X, ldx);
+            } else {
+                gb_utsolve2_body(ab, ldab, kl, ku, n, j0, ncol, ncols, X, ldx);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int64_t p = p1 - 1; p >= p0; --p) {
+            const int64_t j0 = p * GB_NB;
+            const int ncol = static_cast<int>((n - j0 < GB_NB) ? n - j0 : GB_NB);
+            if (D.kind == 1) {
+                gb_usolve2_body(ab, ldab, kl, ku, n, j0, ncol, ncols, X, ldx);
+            } else {
+                if (swaps[p]) gb_ltsolve_body(ab, ldab, kl, ku, n, j0, ncol, ipiv, ncols, X, ldx);
+                else gb_ltsolve2_body(ab, ldab, kl, ku, n, j0, ncol, ncols, X, ldx);
+            }
+            __syncthreads();
+        }
+    }
+}
+// the chain: delta_i for every block, one workgroup of 1,024 lanes per right-hand side: a w x w product per block, rows
+// along the lanes (R is stored column by column: coalesced), the columns cut into GBP_SL slices that are summed through
+// LDS.  delta of the first block in order is zero.
+constexpr int GBP_T = 1024, GBP_SL = 4;
+__global__ __launch_bounds__(GBP_T) void k_gbp_chain(GbPart D, int ncols, const double *__restrict__ bufs, const double *__restrict__ R,
+                                                      const double *__restrict__ X, int64_t ldx, double *__restrict__ delta) {
+    extern __shared__ double sd[]; // cur[w] | part[GBP_SL][w]
+    const int t = blockIdx.x, w = D.w;
+    double *cur = sd, *part = sd + w;
+    const int lane_r = threadIdx.x % (GBP_T / GBP_SL), slice = threadIdx.x / (GBP_T / GBP_SL);
+    const int c_lo = static_cast<int>(static_cast<long long>(w) * slice / GBP_SL), c_hi = static_cast<int>(static_cast<long long>(w) * (slice + 1) / GBP_SL);
+    for (int c = threadIdx.x; c < w; c += GBP_T) cur[c] = 0.0;
+    __syncthreads();
+    for (int step = 0; step < D.P; ++step) {
+        const int i = D.forward() ? step : D.P - 1 - step;
+        double *di = delta + (static_cast<size_t>(i) * ncols + t) * w;
+        for (int c = threadIdx.x; c < w; c += GBP_T) di[c] = cur[c];
+        if (D.last_in_order(i)) break;
+        const int ld = D.ld(i);
+        const int64_t lo = D.lo(i), out0 = D.out0(i);
+        const double *b = bufs + D.rows_before(i) * ncols + static_cast<size_t>(t) * ld; // block i, right-hand side t
+        const double *Ri = R + D.rows_before(i) * w;                                       // block i: column c at c * ld
+        const int ro = static_cast<int>(out0 - lo);
+        const bool zero = D.first_in_order(i);
+        for (int r = lane_r; r < w; r += GBP_T / GBP_SL) {
+            double acc = 0.0;
+            if (!zero) {
+                const double *col = Ri + ro + r;
+                int c = c_lo;
+                for (; c + 8 <= c_hi; c += 8) { // eight loads in flight
+                    double v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = col[static_cast<size_t>(c + q) * ld];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc += v[q] * cur[c + q];
+                }
+                for (; c < c_hi; ++c) acc += col[static_cast<size_t>(c) * ld] * cur[c];
+            }
+            part[slice * w + r] = acc;
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < w; r += GBP_T) {
+            double acc = b[ro + r]; // what the block's own sweep left in its outgoing rows
+            for (int q = 0; q < GBP_SL; ++q) acc += part[q * w + r];
+            // the next block assumed b (kinds 0, 1) or zero (kinds 2, 3) in these rows
+            cur[r] = acc - (D.kind < 2 ? X[out0 + r + t * ldx] : 0.0);
+        }
+        __syncthreads();
+    }
+}
+// own rows of every block: X = private result + R_i delta_i
+__global__ __launch_bounds__(256) void k_gbp_fix(GbPart D, int ncols, const double *__restrict__ bufs, const double *__restrict__ R,
+                                                 const double *__restrict__ delta, double *__restrict__ X, int64_t ldx) {
+    extern __shared__ double sd[]; // [w]
+    const int i = blockIdx.y, t = blockIdx.z, w = D.w;
+    const double *di = delta + (static_cast<size_t>(i) * ncols + t) * w;
+    for (int c = threadIdx.x; c < w; c += 256) sd[c] = di[c];
+    __syncthreads();
+    const int ld = D.ld(i);
+    const int64_t lo = D.lo(i);
+    // the rows block i has the last word on: its own -- except for L^T with the row swaps (kind 3), where the step of
+    // column j exchanges x_j with a row up to kl below it: the w rows after e are rewritten by block i after block i + 1
+    // finished them, so they are block i's, and its own first w rows are block i - 1's
+    int64_t s = D.s(i), e = D.e(i);
+    if (D.kind == 3) {
+        if (i > 0) s += w;
+        if (i < D.P - 1) e += w;
+    }
+    const double *b = bufs + D.rows_before(i) * ncols + static_cast<size_t>(t) * ld;
+    const double *Ri = R + D.rows_before(i) * w;
+    const bool zero = D.first_in_order(i);
+    for (int64_t g = s + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; g < e; g += static_cast<int64_t>(gridDim.x) * 256) {
+        const int r = static_cast<int>(g - lo);
+        double acc = b[r];
+        if (!zero)
+            for (int c = 0; c < w; ++c) acc += Ri[static_cast<size_t>(c) * ld + r] * sd[c];
+        X[g + t * ldx] = acc;
+    }
+}
+
 } // namespace
 
 SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
@@ -923,6 +1106,8 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_solve_loop), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_trail2), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_solve_sparse), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gbp_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gbp_chain), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     }
     SX_HIP(hipMemsetAsync(h->ab, 0, bytes, s));
     SX_HIP(hipMemsetAsync(h->ipiv, 0, sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4), s));
@@ -947,8 +1132,15 @@ SX_API int sx_bandlu_destroy(sx_bandlu *h) {
     (void)hipFree(h->ipiv);
     (void)hipFree(h->d_swaps);
     (void)hipFree(h->d_flags);
+    for (double *r : h->part_R) (void)hipFree(r);
+    (void)hipFree(h->part_buf);
+    (void)hipFree(h->part_delta);
     delete h;
     return SX_OK;
+}
+
+namespace {
+int gb_part_prepare(sx_bandlu *h);
 }
 
 SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
@@ -1001,8 +1193,77 @@ SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_repla
     for (int64_t j = 0; j < n; ++j) cnt += rep[static_cast<size_t>(j)] != 0;
     if (n_replaced_out) *n_replaced_out = cnt;
     if (replaced_host) std::memcpy(replaced_host, rep.data(), sizeof(int32_t) * static_cast<size_t>(n));
+    // the partitioned sweeps' responses now (a few block sweeps), while the memory they need is still free
+    SX_TRY(gb_part_prepare(h));
     return SX_OK;
 }
+
+
+namespace {
+GbPart gb_part_desc(const sx_bandlu *h, int kind) {
+    GbPart D{};
+    D.kind = kind;
+    D.w = (kind == 0 || kind == 3) ? h->kl : h->kl + h->ku;
+    D.LBp = h->part_LBp;
+    D.P = h->part_P;
+    D.n = h->n;
+    D.npanel = (h->n + GB_NB - 1) / GB_NB;
+    D.ld_small = D.LBp * GB_NB + D.w;
+    D.ld_last = static_cast<int>(h->n - D.s(D.P - 1)) + D.w;
+    return D;
+}
+// one sweep of kind `kind` over `ncols` columns held in `bufs` (every block's private rows)
+void gb_part_launch_sweep(sx_bandlu *h, const GbPart &D, int ncols, double *bufs) {
+    hipLaunchKernelGGL(k_gbp_sweep, dim3(static_cast<unsigned>((ncols + GB_CB - 1) / GB_CB), static_cast<unsigned>(D.P)), dim3(GB_T2),
+                       gb_lds_bytes(h->kl + h->ku + GB_NB), h->ctx->stream, h->ab, h->ldab, h->kl, h->ku, h->ipiv, h->d_swaps, D, ncols, bufs);
+}
+// blocks, responses and work buffers of the partitioned sweeps; leaves part_state = -1 when they are not worth it or do
+// not fit (the caller then takes the sequential sweeps)
+int gb_part_prepare(sx_bandlu *h) {
+    h->part_state = -1;
+    if (getenv("SX_BANDLU_SEQ")) return SX_OK;
+    const int64_t npanel = (h->n + GB_NB - 1) / GB_NB;
+    const int kw = h->kl + h->ku;
+    const int min_lbp = (kw + GB_NB - 1) / GB_NB + 1; // a block holds the reach of a panel
+    int64_t P = std::min<int64_t>(128, npanel / std::max(min_lbp, 8));
+    if (P < 4 || kw < 1) return SX_OK;
+    h->part_LBp = static_cast<int>(npanel / P);
+    h->part_P = static_cast<int>(P);
+    if (static_cast<int64_t>(h->part_LBp) * GB_NB < kw) return SX_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SX_OK;
+    size_t need = 0;
+    for (int kind = 0; kind < 4; ++kind) {
+        const GbPart D = gb_part_desc(h, kind);
+        need += sizeof(double) * D.rows_total() * D.w;
+    }
+    const GbPart DU = gb_part_desc(h, 1);
+    need += sizeof(double) * (DU.rows_total() * GB_CB + static_cast<size_t>(DU.P) * GB_CB * DU.w);
+    if (static_cast<double>(need) > 0.05 * static_cast<double>(free_b)) return SX_OK; // (the crossover's tableau takes what is free)
+    hipStream_t s = h->ctx->stream;
+    for (int kind = 0; kind < 4; ++kind) {
+        const GbPart D = gb_part_desc(h, kind);
+        if (hipMalloc(&h->part_R[kind], sizeof(double) * D.rows_total() * D.w) != hipSuccess) return SX_OK;
+        hipLaunchKernelGGL(k_gbp_unit, dim3(64, static_cast<unsigned>(D.P)), dim3(256), 0, s, D, h->part_R[kind]);
+        gb_part_launch_sweep(h, D, D.w, h->part_R[kind]);
+    }
+    if (hipMalloc(&h->part_buf, sizeof(double) * DU.rows_total() * GB_CB) != hipSuccess) return SX_OK;
+    if (hipMalloc(&h->part_delta, sizeof(double) * static_cast<size_t>(DU.P) * GB_CB * DU.w) != hipSuccess) return SX_OK;
+    SX_HIP(hipGetLastError());
+    h->part_state = 1;
+    return SX_OK;
+}
+void gb_part_sweep(sx_bandlu *h, int kind, int ncols, double *X, int64_t ldx) {
+    const GbPart D = gb_part_desc(h, kind);
+    hipStream_t s = h->ctx->stream;
+    hipLaunchKernelGGL(k_gbp_gather, dim3(16, static_cast<unsigned>(D.P)), dim3(256), 0, s, D, ncols, X, ldx, h->part_buf);
+    gb_part_launch_sweep(h, D, ncols, h->part_buf);
+    hipLaunchKernelGGL(k_gbp_chain, dim3(static_cast<unsigned>(ncols)), dim3(GBP_T), sizeof(double) * (1 + GBP_SL) * D.w, s, D, ncols, h->part_buf, h->part_R[kind], X, ldx,
+                       h->part_delta);
+    hipLaunchKernelGGL(k_gbp_fix, dim3(8, static_cast<unsigned>(D.P), static_cast<unsigned>(ncols)), dim3(256), sizeof(double) * D.w, s, D, ncols, h->part_buf,
+                       h->part_R[kind], h->part_delta, X, ldx);
+}
+} // namespace
 
 // In-place solve of nrhs right-hand sides X (column major, ldx >= n): trans = 0: A x = b, 1: A^T x = b.
 SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx) {
@@ -1019,6 +1280,15 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     const int64_t npanel = (n + GB_NB - 1) / GB_NB;
     static const bool slow = getenv("SX_BANDLU_STEPWISE") != nullptr; // the step-by-step panel bodies everywhere (A/B runs, tests)
     (void)npanel;
+    if (nrhs <= GB_CB && !slow) { // a few dense right-hand sides: the sweeps cut into blocks that run side by side
+        if (h->part_state == 0) SX_TRY(gb_part_prepare(h));
+        if (h->part_state == 1) {
+            gb_part_sweep(h, trans ? 2 : 0, static_cast<int>(nrhs), X, ldx);
+            gb_part_sweep(h, trans ? 3 : 1, static_cast<int>(nrhs), X, ldx);
+            SX_HIP(hipGetLastError());
+            return SX_OK;
+        }
+    }
     hipLaunchKernelGGL(k_gb_solve_loop, dim3(grid), dim3(GB_T2), gb_lds_bytes(kl + ku + GB_NB), s, h->ab, h->ldab, kl, ku, n, h->ipiv,
                        h->d_swaps, nrhs, X, ldx, trans ? 1 : 0, slow ? 1 : 0);
     SX_HIP(hipGetLastError());

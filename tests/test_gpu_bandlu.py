@@ -163,3 +163,36 @@ def test_sparse_right_hand_sides(ctx, n, kl, ku, swaps):
         assert np.abs(got - want).max() <= tol, tiny
     assert np.all(want[:, nrhs - 1] == 0.0)
     lu.free()
+
+
+@pytest.mark.parametrize("swaps", [False, True])
+def test_partitioned_sweeps_agree_with_the_sequential_ones(ctx, monkeypatch, swaps):
+    """Up to 8 dense right-hand sides take the partitioned sweeps (blocks of panels side by side + a chain of small
+    products, csrc/sx_bandlu.hip k_gbp_*); SX_BANDLU_SEQ keeps a handle on the sequential ones.  Same solutions to
+    rounding, both orientations, and small residuals."""
+    n, kl, ku = 20000, 117, 113
+    A = dominant_band(n, kl, ku, 7, swaps)
+    kl, ku = kl + int(swaps), ku + int(swaps)
+    monkeypatch.setenv("SX_BANDLU_SEQ", "1")
+    seq, rep, piv = factor(ctx, A, kl, ku)
+    rng = np.random.default_rng(8)
+    M = sp.csc_matrix(A)
+    want = {}
+    for nrhs in (1, 5, 8):
+        B = rng.standard_normal((n, nrhs))
+        for trans in (False, True):
+            X = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+            seq.solve(X, nrhs, n, trans)
+            want[(nrhs, trans)] = (B, X.download().reshape((n, nrhs), order="F"))
+    monkeypatch.delenv("SX_BANDLU_SEQ")
+    par, rep2, piv2 = factor(ctx, A, kl, ku)
+    assert np.array_equal(piv, piv2)
+    for (nrhs, trans), (B, x_seq) in want.items():
+        X = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+        par.solve(X, nrhs, n, trans)
+        got = X.download().reshape((n, nrhs), order="F")
+        scale = np.abs(x_seq).max()
+        assert np.abs(got - x_seq).max() <= 1e-11 * scale, (nrhs, trans)
+        assert np.abs((M.T if trans else M) @ got - B).max() <= 1e-11 * (1 + scale), (nrhs, trans)
+    seq.free()
+    par.free()
