@@ -38,6 +38,18 @@ _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
 PDLP_ITERS = 20000       # first-order stage in front of the crossover ('barrier' runs): iteration limit (0: skip it)
 PDLP_TOL = 1e-9          # ... and its relative KKT tolerance
+
+
+def _pdlp_iterations(m: int, to_band: bool) -> int:
+    """Iterations of the first-order stage.  In front of the dense crossover the full budget: below ~2e4 iterations its
+    crash basis is no better than without the stage (config 2: 238,949 pivots after 5,000 iterations, 692 after 20,000).
+    In front of the sparse crossover a pivot is cheap at 1e5 rows (0.1 ms against 16 us per iteration: 5,000 iterations
+    and 1,105 pivots beat 20,000 and 837 by 0.17 s) and dear at 1e6 (1-2 ms per pivot: 5,000 iterations leave 13,022
+    pivots, 70 s against 17 s) -- so the budget grows with the rows: m / 20 between 5,000 and PDLP_ITERS.  Measured on
+    workloads.netlib_lp only (profiles/r03/lp_1e6.md); SX_PDLP_ITERS overrides."""
+    if not to_band:
+        return PDLP_ITERS
+    return max(5000, min(PDLP_ITERS, m // 20))
 BAND_MIN_ROWS = 30000    # from this many rows on the crossover behind the first-order stage is the sparse one (K16s:
                          # band LU of the starting basis + tableau of the tracked columns) when the basis has that
                          # structure; below, the dense inverse of K16 (8 m^2 bytes) is cheaper to set up
@@ -175,7 +187,9 @@ class HipCaller(SolverCaller):
         d_b, d_c, d_l, d_u = put(self._b), put(self._c), put(self._l), put(self._u)
         self.pdlp = None
         if self._warm is None and getattr(self, "_want_crash", False):
-            iters = int(os.environ.get("SX_PDLP_ITERS", PDLP_ITERS))
+            mode = os.environ.get("SX_LP_CROSSOVER", "auto")
+            to_band = mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS)
+            iters = int(os.environ.get("SX_PDLP_ITERS", _pdlp_iterations(m, to_band)))
             if self._warm_point is not None and iters > 0 and np.asarray(self._warm_point[0]).size == n:
                 # what the reference's backends do with 'barrier' before their crossover: carry the interior point
                 # of the original LP next to the optimum of THIS (perturbed) LP -- first-order stage K16p
@@ -187,8 +201,7 @@ class HipCaller(SolverCaller):
                                      float(os.environ.get("SX_PDLP_TOL", PDLP_TOL)), d_px, d_py)
                 self._warm_point = (d_px.download(), d_py.download())
                 self.pdlp_seconds = time.perf_counter() - t0
-                mode = os.environ.get("SX_LP_CROSSOVER", "auto")
-                if mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS):      # ("dense": K16 whatever the size)
+                if to_band:      # ("dense": K16 whatever the size)
                     try:
                         self._res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_px, 0, 1e-7,
                                                        float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
