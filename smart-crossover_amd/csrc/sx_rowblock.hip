@@ -346,13 +346,44 @@ inline RbLayout layout_of(const sx_rowblock *rb) {
     return RbLayout{rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->nst, rb->nl > 0 ? rb->lprod : nullptr};
 }
 
-// pre-pass of the long rows: products in column order (x streamed), scattered to their slots
+// pre-pass of the long rows: products in column order (x streamed), scattered to their slots.
+// A line of lprod holds 16 consecutive positions of ONE long row, i.e. entries whose columns lie far apart (160,000
+// columns at config 5), so it is completed by many workgroups.  When those sit on different XCDs every L2 writes its
+// part of the line back on its own and the memory side merges them (read-modify-write: measured slower than the
+// gathers it replaces).  Therefore XCD k takes the contiguous k-th eighth of the column-ordered list, tile after tile
+// in dispatch order: the lines a row has open (128 bytes x the number of long rows per XCD) stay in that XCD's L2
+// until they are complete and leave as whole lines.  The three list streams are read once (non-temporal).
+constexpr int RB_LP_TILE = 8 * SX_WG; // entries per workgroup of the pre-pass
 __global__ __launch_bounds__(SX_WG) void k_rb_long_products(int64_t nl, const int32_t *__restrict__ lcol, const double *__restrict__ lval,
                                                             const int32_t *__restrict__ le, const double *__restrict__ x,
                                                             double *__restrict__ lprod, const RbCgState *st) {
     if (st && st->done) return;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
-    if (i < nl) lprod[le[i]] = lval[i] * x[lcol[i]];
+    const int64_t ntiles = (nl + RB_LP_TILE - 1) / RB_LP_TILE;
+    const int64_t per = (ntiles + 7) >> 3;
+    const int64_t tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || tile >= ntiles) return;
+    const int64_t i0 = tile * RB_LP_TILE + threadIdx.x;
+    int32_t c[8], e[8];
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int64_t i = i0 + q * SX_WG;
+        const bool ok = i < nl;
+        c[q] = ok ? __builtin_nontemporal_load(lcol + i) : 0;
+        e[q] = ok ? __builtin_nontemporal_load(le + i) : -1;
+        v[q] = ok ? __builtin_nontemporal_load(lval + i) : 0.0;
+    }
+    double xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xv[q] = x[c[q]];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (e[q] >= 0) lprod[e[q]] = v[q] * xv[q];
+}
+
+inline unsigned rb_lp_grid(int64_t nl) {
+    const int64_t ntiles = (nl + RB_LP_TILE - 1) / RB_LP_TILE;
+    return static_cast<unsigned>(((ntiles + 7) >> 3) << 3);
 }
 
 } // namespace
@@ -363,7 +394,7 @@ int sx_rb_score_rows(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const do
     const int swz = ctx->opt_xcd_swizzle;
     const unsigned grid = swz ? static_cast<unsigned>(((rb->nst + 7) >> 3) << 3) : static_cast<unsigned>(rb->nst);
     if (rb->nl > 0)
-        hipLaunchKernelGGL(k_rb_long_products, dim3(static_cast<unsigned>((rb->nl + SX_WG - 1) / SX_WG)), dim3(SX_WG), 0, ctx->stream,
+        hipLaunchKernelGGL(k_rb_long_products, dim3(rb_lp_grid(rb->nl)), dim3(SX_WG), 0, ctx->stream,
                            rb->nl, rb->lcol, rb->lval, rb->le, x, rb->lprod, static_cast<const RbCgState *>(nullptr));
     hipLaunchKernelGGL(k_rb_score_rows, dim3(grid), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, x, ncols, b, y,
                        gamma_dual, s_p, flag);
@@ -378,7 +409,7 @@ int sx_rb_cg_a(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const void *cg
     if (swz) g &= ~static_cast<int64_t>(7);
     if (g < 1) g = 1;
     if (rb->nl > 0)
-        hipLaunchKernelGGL(k_rb_long_products, dim3(static_cast<unsigned>((rb->nl + SX_WG - 1) / SX_WG)), dim3(SX_WG), 0, ctx->stream,
+        hipLaunchKernelGGL(k_rb_long_products, dim3(rb_lp_grid(rb->nl)), dim3(SX_WG), 0, ctx->stream,
                            rb->nl, rb->lcol, rb->lval, rb->le, w, rb->lprod, static_cast<const RbCgState *>(cg_state));
     hipLaunchKernelGGL(k_rb_cg_a, dim3(static_cast<unsigned>(g)), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz,
                        static_cast<const RbCgState *>(cg_state), w, ncols, xs, p, q, partial);

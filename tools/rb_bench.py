@@ -36,8 +36,10 @@ def main():
     k2_bytes = 12 * A.nnz + 8 * n + 33 * m
     out = {}
     mats = {}
-    for name, opt in (("plain", 0), ("blocked", 1)):
+    variants = (("plain", 0, 0), ("blocked", 1, 0), ("staged", 1, 1))
+    for name, opt, stage in variants:
         ctx.set_option("rowblock", opt)
+        ctx.set_option("rb_stage_long", stage)
         mats[name] = ctx.row_shard(A)
         s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
         ctx.sync()
@@ -48,9 +50,9 @@ def main():
         out[name] = (s_p, flag, first)
         info = mats[name].rowblock()
         print(f"{name}: first call {first * 1e3:.1f} ms, layout {info}", flush=True)
-    times = {"plain": [], "blocked": []}
+    times = {"plain": [], "blocked": [], "staged": []}
     for _ in range(args.rounds):
-        for name, opt in (("plain", 0), ("blocked", 1)):
+        for name, opt, stage in variants:
             ctx.set_option("rowblock", opt)
             s_p, flag, _ = out[name]
             ctx.score_rows(mats[name], d_x, d_b, d_y, 1e-3, s_p, flag)
@@ -61,8 +63,10 @@ def main():
             times[name].append(ctx.marker_elapsed(0, 1) / args.reps)
     same = (np.array_equal(out["plain"][0].download().view(np.uint64), out["blocked"][0].download().view(np.uint64))
             and np.array_equal(out["plain"][1].download(), out["blocked"][1].download()))
+    same = same and (np.array_equal(out["plain"][0].download().view(np.uint64), out["staged"][0].download().view(np.uint64))
+                     and np.array_equal(out["plain"][1].download(), out["staged"][1].download()))
     print(f"bit-identical: {same}")
-    for name in ("plain", "blocked"):
+    for name in ("plain", "blocked", "staged"):
         t = np.array(times[name])
         print(f"K2 {name:8s} {np.median(t):.4f} ms (min {t.min():.4f}) = {k2_bytes / np.median(t) / 1e6:.0f} GB/s algorithmic, "
               f"{k2_bytes / np.median(t) / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
