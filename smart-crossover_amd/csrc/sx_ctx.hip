@@ -119,6 +119,8 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "rowblock")) {
         SX_REQUIRE(value >= -1 && value <= 1, "rowblock must be -1 (auto), 0 (off) or 1 (whenever possible)");
         ctx->opt_rowblock = static_cast<int>(value);
+    } else if (!strcmp(key, "run_prefetch")) {
+        ctx->opt_run_prefetch = value ? 1 : 0;
     } else if (!strcmp(key, "rb_stage_long")) {
         ctx->opt_rb_stage_long = value ? 1 : 0; // (read when a layout is built)
     } else if (!strcmp(key, "spx_check")) {

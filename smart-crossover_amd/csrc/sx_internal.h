@@ -90,6 +90,7 @@ struct sx_ctx {
     int opt_netdual = -1;    // K16d dual network simplex on the whole GPU: -1 / 1 whenever it applies, 0 never
     int opt_nd_grid = 0;     // K16d: workgroups of its cooperative grid (0: by size)
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
+    int opt_run_prefetch = 0;  // windowed column walk (K1, K10): loads one step ahead (sx_runwalk.h); 0: tile by tile
     int opt_rb_stage_long = 0; // row-blocked layout: products of the long rows by a column-ordered pre-pass (0: gather in the
                                // walk).  Measured SLOWER (K2 0.442 vs 0.381 ms at config 5: the 1e7 scattered 8-byte stores cost more
                                // than the 1e7 gathered lines they replace; profiles/r03/experiments/k2_long_row_staging.md): off

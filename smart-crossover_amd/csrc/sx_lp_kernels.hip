@@ -5,7 +5,7 @@
 #include "sx_internal.h"
 #include "sx_rowblock.h"
 #include "sx_segwalk.h"
-#include "sx_window.h"
+#include "sx_runwalk.h"
 
 #include <cmath>
 
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
 
 // K1 behind an LDS operand window: one workgroup scores RUN consecutive tiles per window load
 // (sx_window.h).  Same sums, same roundings, same outputs as k_score_columns.
-template <int RUN>
+template <int RUN, int PF>
 __global__ __launch_bounds__(SX_WG) void k_score_columns_lw(
     const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
@@ -74,6 +74,32 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns_lw(
     const int64_t wlo = win_lo[(t0 + t1 - 1) >> 1]; // window of the run's middle tile
     sx_window_fill(win, y, wlo, m);
     __syncthreads();
+    if constexpr (PF) { // loads one step ahead (sx_runwalk.h)
+        struct Ops {
+            double cj, xj, lj, uj;
+        };
+        auto pre = [&](int64_t seg) {
+            Ops o{c[seg], 0.0, 0.0, 0.0};
+            if (code) { // uniform
+                o.xj = x[seg];
+                o.lj = l[seg];
+                o.uj = u[seg];
+            }
+            return o;
+        };
+        auto epi = [&](int64_t j, bool valid, double sum, const Ops &o) {
+            if (!valid) return;
+            const double sd = o.cj - sum;
+            if (s_d) s_d[j] = sd;
+            if (code) {
+                const bool low = (o.xj - o.lj) < (gamma * sd);
+                const bool up = (o.uj - o.xj) < (gamma * (-sd));
+                code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
+            }
+        };
+        sx_runwalk<RUN>(tiles, t0, t1, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, pre, epi);
+        return;
+    }
     for (int64_t tile = t0; tile < t1; ++tile) {
         double acc[1];
         int64_t j;
@@ -227,8 +253,8 @@ __global__ __launch_bounds__(SX_WG) void k_price(
 }
 
 // K10 behind the LDS operand window: grid-stride over runs of RUN tiles, one window load per run
-template <int RUN>
-__global__ __launch_bounds__(SX_WG) void k_price_lw(
+template <int RUN, int PF>
+__global__ __launch_bounds__(SX_WG, 4) void k_price_lw(
     const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int32_t *__restrict__ win_lo,
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
     int64_t m, const double *__restrict__ y, const double *__restrict__ c, const int8_t *__restrict__ vbasis,
@@ -253,6 +279,27 @@ __global__ __launch_bounds__(SX_WG) void k_price_lw(
         __syncthreads(); // the previous run's gathers are done with the window
         sx_window_fill(win, y, wlo, m);
         __syncthreads();
+        if constexpr (PF) { // loads one step ahead (sx_runwalk.h)
+            struct Ops {
+                double cj;
+                int vbj;
+            };
+            auto pre = [&](int64_t seg) {
+                Ops o{c[seg], 0};
+                if (vbasis) o.vbj = vbasis[seg]; // uniform
+                return o;
+            };
+            auto epi = [&](int64_t j, bool valid, double sum, const Ops &o) {
+                if (!valid) return;
+                double rc = o.cj - sum;
+                if (o.vbj == -2) rc = -rc;
+                if (rc_out) rc_out[j] = rc;
+                bad += (rc >= -tol) ? 0 : 1;
+                if (rc == rc) price_combine(v, ix, rc, j);
+            };
+            sx_runwalk<RUN>(tiles, t0, t1, colptr, rowidx, val, sx_stage_win{y, win, wlo}, lds, pre, epi);
+            continue;
+        }
         for (int64_t t = t0; t < t1; ++t) {
             double acc[1];
             int64_t j;
@@ -521,10 +568,16 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
 #define SX_LAUNCH_K1W(R)                                                                           \
     do {                                                                                           \
         const int64_t nruns = (A->n_csc_tiles + (R)-1) / (R);                                      \
-        hipLaunchKernelGGL((k_score_columns_lw<R>), dim3(walk_grid(ctx, nruns)), dim3(SX_WG), 0,   \
-                           ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo,          \
-                           A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d,    \
-                           code);                                                                  \
+        if (ctx->opt_run_prefetch)                                                                 \
+            hipLaunchKernelGGL((k_score_columns_lw<R, 1>), dim3(walk_grid(ctx, nruns)), dim3(SX_WG), 0, \
+                               ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo,      \
+                               A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d, \
+                               code);                                                              \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_score_columns_lw<R, 0>), dim3(walk_grid(ctx, nruns)), dim3(SX_WG), 0, \
+                               ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo,      \
+                               A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d, \
+                               code);                                                              \
     } while (0)
         if (run == 8) SX_LAUNCH_K1W(8);
         else if (run == 4) SX_LAUNCH_K1W(4);
@@ -658,9 +711,16 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     SX_TRY(sx_window_run_csc(ctx, A, &run));
     if (run) {
 #define SX_LAUNCH_K10W(R)                                                                          \
-    hipLaunchKernelGGL((k_price_lw<R>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,       \
-                       A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val,     \
-                       A->m, y, c, vbasis, tol, rc, partial)
+    do {                                                                                           \
+        if (ctx->opt_run_prefetch)                                                                 \
+            hipLaunchKernelGGL((k_price_lw<R, 1>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, \
+                               A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, \
+                               A->m, y, c, vbasis, tol, rc, partial);                              \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_price_lw<R, 0>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, \
+                               A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, \
+                               A->m, y, c, vbasis, tol, rc, partial);                              \
+    } while (0)
         if (run == 8) SX_LAUNCH_K10W(8);
         else if (run == 4) SX_LAUNCH_K10W(4);
         else if (run == 2) SX_LAUNCH_K10W(2);

@@ -50,6 +50,8 @@ def main():
         variants = [(1, 0, 4096, w) for w in (0, 1, 4, -1)]
     elif args.variants == "policy":   # cache policy of the streamed loads (see sx_segwalk.h)
         variants = [(1, p, 4096, 0) for p in (0, 1, 2, 16, 17, 18)]
+    elif args.variants == "runwalk":  # windowed walk tile by tile (0) / with its loads one step ahead (1), sx_runwalk.h
+        variants = [(1, 0, 4096, -1, pf) for pf in (0, 1)]
     res = {v: {"k1": [], "k2": [], "k10": []} for v in variants}
     ref = None
     for rnd in range(args.rounds):
@@ -58,6 +60,8 @@ def main():
             ctx.set_option("nt_stream", v[1])
             ctx.set_option("chunk", v[2])
             ctx.set_option("window", v[3])
+            if len(v) > 4:
+                ctx.set_option("run_prefetch", v[4])
             ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)   # warm
             ctx.marker(0)
             for _ in range(args.reps):
