@@ -37,7 +37,7 @@ __device__ __forceinline__ int64_t sx_readlane64(int64_t v, int lane) {
 // that and was slower than the plain one.  The tile loop is unrolled (static register sets), the chunk loop is not:
 // the next chunk's entries are requested at the top of an iteration and waited for at its bottom (the copy into the
 // current set), behind the multiply, the barrier and the adds.
-template <int RUN, class Stage, class Pre, class Epi>
+template <int RUN, class Stage /* sx_stage_win */, class Pre, class Epi>
 __device__ __forceinline__ void sx_runwalk(const int64_t *__restrict__ tiles, int64_t t0, int64_t t1,
                                            const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                            const double *__restrict__ val, const Stage &stage,
@@ -95,16 +95,32 @@ __device__ __forceinline__ void sx_runwalk(const int64_t *__restrict__ tiles, in
             do { // a tile without entries takes one empty turn
                 const int64_t nb = base + SXL_CHUNK;
                 const bool same = nb < p_hi;
-                double o0[1], o1[1], o2[1], o3[1];
-                stage(Q.v01.x, Q.i.x, o0);
-                stage(Q.v01.y, Q.i.y, o1);
-                stage(Q.v23.x, Q.i.z, o2);
-                stage(Q.v23.y, Q.i.w, o3);
-                // the gathers of the stage are FLAT loads (LDS window or global memory, selected per lane): their
-                // results are waited for with vmcnt(0), which would drain the request below as well if it went first
+                // Gathers in two unconditional halves -- the window by ds_read (clamped slot), the rows outside it by a
+                // global load (lanes inside the window all read vec[wlo]: one line) -- instead of the per-lane select
+                // of sx_stage_win, which the compiler turns into FLAT loads: flat results are waited for with
+                // vmcnt(0) and would drain the request of the next chunk.  Order: global gathers, then the request,
+                // then the LDS reads; the products wait for the gathers only (vmcnt(3)).
+                const int32_t gi[4] = {Q.i.x, Q.i.y, Q.i.z, Q.i.w};
+                double yg[4], yl[4];
+                bool in[4];
+                uint32_t dd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t d = static_cast<uint64_t>(static_cast<int64_t>(gi[q]) - stage.wlo);
+                    in[q] = d < static_cast<uint64_t>(SXL_CAP);
+                    dd[q] = in[q] ? static_cast<uint32_t>(d) : 0u;
+                    yg[q] = stage.vec[in[q] ? stage.wlo : static_cast<int64_t>(gi[q])];
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 load_quad(same ? nb : nbase0, same ? p_hi : np_hi, Qn);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) yl[q] = stage.win[dd[q]];
+                double o0[1], o1[1], o2[1], o3[1];
+                o0[0] = Q.v01.x * (in[0] ? yl[0] : yg[0]);
+                o1[0] = Q.v01.y * (in[1] ? yl[1] : yg[1]);
+                o2[0] = Q.v23.x * (in[2] ? yl[2] : yg[2]);
+                o3[0] = Q.v23.y * (in[3] ? yl[3] : yg[3]);
                 double2 *dst = reinterpret_cast<double2 *>(&lds.v[0][tid * 4]);
                 dst[0] = make_double2(o0[0], o1[0]);
                 dst[1] = make_double2(o2[0], o3[0]);

@@ -6,7 +6,7 @@ build) warm-started from the basis that point indicates -- what the reference's 
 simplex from scratch do not finish on these sub-problems (profiles/r03/lp_1e6_highs.json); this is the CPU path that
 might.  Development / measurement tool: bench.py reads the record it writes.
 
-    python tools/cpu_lp_path.py [m=100000 n=1000000] [iters=20000] [limit=7200] [out=path.json]
+    python tools/cpu_lp_path.py [which=c2 | m=100000 n=1000000] [iters=20000] [limit=7200] [out=path.json]
 """
 import json
 import os
@@ -28,7 +28,8 @@ def main():
     from oracle import lp_path as L
     from oracle import pdlp as P
     import scipy.optimize._highspy._core as hc
-    inst = workloads.netlib_lp(m, n)
+    inst = workloads.config2() if kw.get("which") == "c2" else workloads.netlib_lp(m, n)
+    m, n = inst.A.shape
     t0 = time.perf_counter()
     res = L.scoring_pass(inst.A, inst.b, inst.c, inst.l, inst.u, inst.x, inst.y)
     c_pt, _ = L.perturbed_cost_full(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense, inst.x, False, explicit=False)
@@ -106,7 +107,7 @@ def main():
     obj = float(info.objective_function_value)
     rec = {"cpu_kind": "port of the device's route: numpy/scipy oracle (matrix-free CG) + oracle/pdlp.py first-order stage + "
                        "HiGHS' simplex (scipy's bundled build) warm-started from the basis that point indicates",
-           "sub_problem": f"{ms} x {ns}, {A.nnz} entries (workloads.netlib_lp({m}, {n}))",
+           "sub_problem": f"{ms} x {ns}, {A.nnz} entries (workloads.{'config2()' if kw.get('which') == 'c2' else f'netlib_lp({m}, {n})'})",
            "cpu_host_arithmetic_s": t1 - t0, "cpu_first_order_s": t2 - t1, "cpu_first_order_iterations": int(r["iters"]),
            "cpu_crossover_s": t4 - t3, "cpu_resolve_s": t4 - t1, "cpu_total_s": t4 - t0,
            "cpu_resolve_status": "OPTIMAL" if status == "Optimal" else status, "highs_return": str(st),
