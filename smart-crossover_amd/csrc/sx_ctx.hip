@@ -1,6 +1,7 @@
 // Context, memory plumbing, stopwatch and matrix residency of libsxhip.so.
 #include "sx_internal.h"
 #include "sx_rowblock.h"
+#include "sx_slabs.h"
 
 #include <algorithm>
 
@@ -119,6 +120,9 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "rowblock")) {
         SX_REQUIRE(value >= -1 && value <= 1, "rowblock must be -1 (auto), 0 (off) or 1 (whenever possible)");
         ctx->opt_rowblock = static_cast<int>(value);
+    } else if (!strcmp(key, "slabs")) {
+        SX_REQUIRE(value >= -1 && value != 1 && value <= 256, "slabs must be -1 (auto), 0 (never) or 2..256");
+        ctx->opt_slabs = static_cast<int>(value);
     } else if (!strcmp(key, "run_prefetch")) {
         ctx->opt_run_prefetch = value ? 1 : 0;
     } else if (!strcmp(key, "rb_stage_long")) {
@@ -451,6 +455,8 @@ SX_API int sx_matrix_destroy(sx_matrix *A) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     sx_rowblock_free(A->rb);
+    sx_slabs_free(A->slabs[0]);
+    sx_slabs_free(A->slabs[1]);
     delete A;
     return SX_OK;
 }

@@ -90,6 +90,7 @@ struct sx_ctx {
     int opt_netdual = -1;    // K16d dual network simplex on the whole GPU: -1 / 1 whenever it applies, 0 never
     int opt_nd_grid = 0;     // K16d: workgroups of its cooperative grid (0: by size)
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
+    int opt_slabs = -1;        // operand slabs of a walk without locality (sx_slabs.h): -1 auto, 0 never, R >= 2: R slabs
     int opt_run_prefetch = 0;  // windowed column walk (K1, K10): loads one step ahead (sx_runwalk.h); 0: tile by tile
     int opt_rb_stage_long = 0; // row-blocked layout: products of the long rows by a column-ordered pre-pass (0: gather in the
                                // walk).  Measured SLOWER (K2 0.442 vs 0.381 ms at config 5: the 1e7 scattered 8-byte stores cost more
@@ -148,6 +149,9 @@ struct sx_matrix {
     // optional column-blocked copy of the rows (sx_rowblock.h), built on first use of a row walk
     mutable struct sx_rowblock *rb = nullptr;
     mutable int rb_tried = 0; // 1: the automatic rule has spoken, 2: so has a forced build
+    // optional operand slabs of a walk without locality (sx_slabs.h): [0] row walk, [1] column walk
+    mutable struct sx_slabs *slabs[2] = {nullptr, nullptr};
+    mutable int slabs_tried[2] = {0, 0}; // the slab count slabs[] was built (or refused) for
 };
 
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,

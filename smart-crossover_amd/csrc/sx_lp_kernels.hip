@@ -6,6 +6,7 @@
 #include "sx_rowblock.h"
 #include "sx_segwalk.h"
 #include "sx_runwalk.h"
+#include "sx_slabs.h"
 
 #include <cmath>
 
@@ -25,17 +26,18 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
     const double *__restrict__ val, const double *__restrict__ y, const double *__restrict__ c,
     const double *__restrict__ x, const double *__restrict__ l, const double *__restrict__ u,
-    double gamma, double *__restrict__ s_d, uint8_t *__restrict__ code) {
+    double gamma, double *__restrict__ s_d, uint8_t *__restrict__ code, const double *__restrict__ carry_in) {
     __shared__ sx_walk_lds<1, CHUNK> lds;
     const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
     if (tile >= ntiles) return;
-    double acc[1];
+    double acc[1] = {0.0};
     int64_t j;
     bool valid;
     // the epilogue's operands are requested before the walk so their latency hides under it
     double cj = 0.0, xj = 0.0, lj = 0.0, uj = 0.0;
     auto pre = [&](int64_t seg, bool ok) {
         if (ok) {
+            if (carry_in) acc[0] = carry_in[seg]; // last slab of a slabbed walk (sx_slabs.h): the sum continues
             cj = c[seg];
             if (code) {
                 xj = x[seg];
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
             }
         }
     };
-    sx_segwalk<1, CHUNK, NT>(tiles, tile, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre);
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre, true);
     if (!valid) return;
     const double sd = cj - acc[0];
     if (s_d) s_d[j] = sd;
@@ -53,6 +55,26 @@ __global__ __launch_bounds__(SX_WG) void k_score_columns(
         const bool up = (uj - xj) < (gamma * (-sd));
         code[j] = static_cast<uint8_t>((low ? SX_CODE_LOW : 0u) | (up ? SX_CODE_UP : 0u));
     }
+}
+
+// A pass of a slabbed walk that is not the last one (sx_slabs.h): carry[seg] (+0.0 in the first pass) continued by
+// the slab's products, left to right.  Serves the column and the row walk alike.
+template <int CHUNK, int NT>
+__global__ __launch_bounds__(SX_WG) void k_slab_accumulate(
+    const int64_t *__restrict__ tiles, int64_t ntiles, int swizzle, const int64_t *__restrict__ ptr,
+    const int32_t *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ operand,
+    int first, double *__restrict__ carry) {
+    __shared__ sx_walk_lds<1, CHUNK> lds;
+    const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
+    if (tile >= ntiles) return;
+    double acc[1] = {0.0};
+    int64_t seg;
+    bool valid;
+    auto pre = [&](int64_t sg, bool ok) {
+        if (ok && !first) acc[0] = carry[sg];
+    };
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, ptr, idx, val, StageDot{operand}, lds, seg, valid, acc, pre, true);
+    if (valid) carry[seg] = acc[0];
 }
 
 // K1 behind an LDS operand window: one workgroup scores RUN consecutive tiles per window load
@@ -136,21 +158,22 @@ __global__ __launch_bounds__(SX_WG) void k_score_rows(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ x, const double *__restrict__ b,
     const double *__restrict__ y, double gamma_dual, double *__restrict__ s_p,
-    uint8_t *__restrict__ flag) {
+    uint8_t *__restrict__ flag, const double *__restrict__ carry_in) {
     __shared__ sx_walk_lds<1, CHUNK> lds;
     const int64_t tile = sx_tile_of_block(blockIdx.x, ntiles, swizzle);
     if (tile >= ntiles) return;
-    double acc[1];
+    double acc[1] = {0.0};
     int64_t i;
     bool valid;
     double bi = 0.0, yi = 0.0;
     auto pre = [&](int64_t seg, bool ok) {
         if (ok) {
+            if (carry_in) acc[0] = carry_in[seg]; // last slab of a slabbed walk (sx_slabs.h)
             bi = b[seg];
             if (flag) yi = y[seg];
         }
     };
-    sx_segwalk<1, CHUNK, NT>(tiles, tile, rowptr, colidx, val, StageDot{x}, lds, i, valid, acc, pre);
+    sx_segwalk<1, CHUNK, NT>(tiles, tile, rowptr, colidx, val, StageDot{x}, lds, i, valid, acc, pre, true);
     if (!valid) return;
     const double sp = bi - acc[0];
     if (s_p) s_p[i] = sp;
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(SX_WG) void k_price(
     const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
     const double *__restrict__ val, const double *__restrict__ y, const double *__restrict__ c,
     const int8_t *__restrict__ vbasis, double tol, double *__restrict__ rc_out,
-    PricePartial *__restrict__ partial) {
+    PricePartial *__restrict__ partial, const double *__restrict__ carry_in) {
     __shared__ sx_walk_lds<1, CHUNK> lds;
     double v = 0.0;
     long long ix = -1, bad = 0;
@@ -228,18 +251,19 @@ __global__ __launch_bounds__(SX_WG) void k_price(
         t_step = gridDim.x >> 3;
     }
     for (; t < t_end; t += t_step) {
-        double acc[1];
+        double acc[1] = {0.0};
         int64_t j;
         bool valid;
         double cj = 0.0;
         int vbj = 0; // requested before the walk so that their latency hides under it
         auto pre = [&](int64_t seg, bool ok) {
             if (ok) {
+                if (carry_in) acc[0] = carry_in[seg]; // last slab of a slabbed walk (sx_slabs.h)
                 cj = c[seg];
                 if (vbasis) vbj = vbasis[seg];
             }
         };
-        sx_segwalk<1, CHUNK, NT>(tiles, t, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre);
+        sx_segwalk<1, CHUNK, NT>(tiles, t, colptr, rowidx, val, StageDot{y}, lds, j, valid, acc, pre, true);
         if (valid) {
             double rc = cj - acc[0];
             if (vbj == -2) rc = -rc;
@@ -531,6 +555,18 @@ inline unsigned walk_grid(const sx_ctx *ctx, int64_t ntiles) {
     return static_cast<unsigned>(((ntiles + 7) >> 3) << 3);
 }
 
+// passes 0 .. R-2 of a slabbed walk: S->carry holds the running sums the last pass starts from.  The entry stream is
+// read once and non-temporal, so that it does not displace the operand slab from L2.
+static int slab_passes(sx_ctx *ctx, const sx_slabs *S, const double *operand) {
+    for (int s = 0; s + 1 < S->R; ++s) {
+        const sx_slab &L = S->slab[s];
+        hipLaunchKernelGGL((k_slab_accumulate<4096, 2>), dim3(walk_grid(ctx, L.ntiles)), dim3(SX_WG), 0, ctx->stream, L.tiles,
+                           L.ntiles, ctx->opt_xcd_swizzle, L.ptr, L.idx, L.val, operand + L.off, s == 0 ? 1 : 0, S->carry);
+    }
+    SX_HIP(hipGetLastError());
+    return SX_OK;
+}
+
 #define SX_DISPATCH_VARIANT(ctx, LAUNCH)                                                           \
     do {                                                                                           \
         if ((ctx)->opt_chunk == 2048) {                                                            \
@@ -587,11 +623,24 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
         SX_HIP(hipGetLastError());
         return SX_OK;
     }
+    {   // no locality and an operand beyond L2: slab after slab (sx_slabs.h), the epilogue in the last pass
+        const sx_slabs *S = nullptr;
+        SX_TRY(sx_slabs_get(ctx, A, 1, &S));
+        if (S) {
+            SX_TRY(slab_passes(ctx, S, y));
+            const sx_slab &L = S->slab[S->R - 1];
+            hipLaunchKernelGGL((k_score_columns<4096, 2>), dim3(walk_grid(ctx, L.ntiles)), dim3(SX_WG), 0, ctx->stream, L.tiles,
+                               L.ntiles, ctx->opt_xcd_swizzle, L.ptr, L.idx, L.val, y + L.off, c, x, l, u, gamma, s_d, code,
+                               S->carry);
+            SX_HIP(hipGetLastError());
+            return SX_OK;
+        }
+    }
     const unsigned grid = walk_grid(ctx, A->n_csc_tiles);
 #define SX_LAUNCH_K1(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_columns<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,        \
                        A->csc_tiles, A->n_csc_tiles, ctx->opt_xcd_swizzle, A->csc_ptr, A->csc_idx, \
-                       A->csc_val, y, c, x, l, u, gamma, s_d, code)
+                       A->csc_val, y, c, x, l, u, gamma, s_d, code, static_cast<const double *>(nullptr))
     SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K1);
 #undef SX_LAUNCH_K1
     SX_HIP(hipGetLastError());
@@ -612,11 +661,24 @@ SX_API int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, c
         SX_TRY(sx_rowblock_get(ctx, A, &rb));
         if (rb) return sx_rb_score_rows(ctx, rb, A->n, x, b, y, gamma_dual, s_p, flag);
     }
+    {   // no locality and an operand beyond L2: slab after slab (sx_slabs.h)
+        const sx_slabs *S = nullptr;
+        SX_TRY(sx_slabs_get(ctx, A, 0, &S));
+        if (S) {
+            SX_TRY(slab_passes(ctx, S, x));
+            const sx_slab &L = S->slab[S->R - 1];
+            hipLaunchKernelGGL((k_score_rows<4096, 2>), dim3(walk_grid(ctx, L.ntiles)), dim3(SX_WG), 0, ctx->stream, L.tiles,
+                               L.ntiles, ctx->opt_xcd_swizzle, L.ptr, L.idx, L.val, x + L.off, b, y, gamma_dual, s_p, flag,
+                               S->carry);
+            SX_HIP(hipGetLastError());
+            return SX_OK;
+        }
+    }
     const unsigned grid = walk_grid(ctx, A->n_csr_tiles);
 #define SX_LAUNCH_K2(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_rows<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,           \
                        A->csr_tiles, A->n_csr_tiles, ctx->opt_xcd_swizzle, A->csr_ptr, A->csr_idx, \
-                       A->csr_val, x, b, y, gamma_dual, s_p, flag)
+                       A->csr_val, x, b, y, gamma_dual, s_p, flag, static_cast<const double *>(nullptr))
     SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K2);
 #undef SX_LAUNCH_K2
     SX_HIP(hipGetLastError());
@@ -731,10 +793,27 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
         SX_HIP(hipGetLastError());
         return SX_OK;
     }
+    {   // no locality and an operand beyond L2: slab after slab (sx_slabs.h), pricing in the last pass
+        const sx_slabs *S = nullptr;
+        SX_TRY(sx_slabs_get(ctx, A, 1, &S));
+        if (S) {
+            SX_TRY(slab_passes(ctx, S, y));
+            const sx_slab &L = S->slab[S->R - 1];
+            const int swl = (ctx->opt_xcd_swizzle && L.ntiles >= 64) ? 1 : 0;
+            int nbl = static_cast<int>(L.ntiles < PRICE_GRID ? L.ntiles : PRICE_GRID);
+            if (swl) nbl &= ~7;
+            if (nbl < 1) nbl = 1;
+            hipLaunchKernelGGL((k_price<4096, 2>), dim3(nbl), dim3(SX_WG), 0, ctx->stream, L.tiles, L.ntiles, swl, L.ptr, L.idx,
+                               L.val, y + L.off, c, vbasis, tol, rc, partial, S->carry);
+            hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial, static_cast<int64_t>(nbl), result_dev);
+            SX_HIP(hipGetLastError());
+            return SX_OK;
+        }
+    }
 #define SX_LAUNCH_K10(CH, NTV)                                                                     \
     hipLaunchKernelGGL((k_price<CH, NTV>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,    \
                        A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx, A->csc_val, y, c, vbasis, tol, \
-                       rc, partial)
+                       rc, partial, static_cast<const double *>(nullptr))
     SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K10);
 #undef SX_LAUNCH_K10
     hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial,

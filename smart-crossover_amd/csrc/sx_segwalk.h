@@ -105,7 +105,7 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, in
                                            const int32_t *__restrict__ idx,
                                            const double *__restrict__ val, const Stage &stage,
                                            sx_walk_lds<NACC, CHUNK> &lds, int64_t &seg, bool &valid,
-                                           double (&acc)[NACC], const Pre &pre = Pre()) {
+                                           double (&acc)[NACC], const Pre &pre = Pre(), const bool keep = false) {
     const int tid = threadIdx.x;
     const int64_t s0 = tiles[tile];
     const int64_t s1 = tiles[tile + 1];
@@ -119,8 +119,10 @@ __device__ __forceinline__ void sx_segwalk(const int64_t *__restrict__ tiles, in
         cs = ptr[seg];
         ce = ptr[seg + 1];
     }
+    if (!keep) { // keep: the sums continue from what the caller (or its `pre`) left in acc[] -- sx_slabs.h
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+        for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    }
 
     for (int64_t base = p_lo & ~static_cast<int64_t>(3); base < p_hi; base += CHUNK) {
         // ---- stage: CHUNK / SX_SWEEP sweeps of 1024 entries

@@ -52,6 +52,8 @@ def main():
         variants = [(1, p, 4096, 0) for p in (0, 1, 2, 16, 17, 18)]
     elif args.variants == "runwalk":  # windowed walk tile by tile (0) / with its loads one step ahead (1), sx_runwalk.h
         variants = [(1, 0, 4096, -1, pf) for pf in (0, 1)]
+    elif args.variants == "slabs":    # operand slabs of the walks without locality (sx_slabs.h): never / automatic
+        variants = [(1, 0, 4096, -1, 0, sl) for sl in ([0, -1] + [int(q) for q in os.environ.get("SLABS", "").split(",") if q])]
     res = {v: {"k1": [], "k2": [], "k10": []} for v in variants}
     ref = None
     for rnd in range(args.rounds):
@@ -62,7 +64,10 @@ def main():
             ctx.set_option("window", v[3])
             if len(v) > 4:
                 ctx.set_option("run_prefetch", v[4])
-            ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)   # warm
+            if len(v) > 5:
+                ctx.set_option("slabs", v[5])
+            ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)   # warm (layouts are built on first use)
+            ctx.score_rows(dR, d["x"], d["b"], d["y"], 1e-3, s_p, flag)
             ctx.marker(0)
             for _ in range(args.reps):
                 ctx.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)
@@ -87,7 +92,7 @@ def main():
     print(f"workload {args.workload}/{structure} window={args.window}: K1 bytes {k1_bytes/1e9:.3f} GB, K2 bytes {k2_bytes/1e9:.3f} GB")
     print("swz nt chunk win |  K1 med ms   min ms   GB/s(med) |  K2 med ms   min ms   GB/s(med) | K10 med ms   min ms   GB/s(med)")
     for v in variants:
-        extra = f"/{v[4]}" if len(v) > 4 else ""
+        extra = "".join(f"/{q}" for q in v[4:])
         a, b, p10 = np.array(res[v]["k1"]), np.array(res[v]["k2"]), np.array(res[v]["k10"])
         print(f" {v[0]} {v[1]:2d}  {v[2]:4d} {v[3]:3d}{extra} |  {np.median(a):8.4f} {a.min():8.4f} {k1_bytes/np.median(a)/1e6:9.0f} |"
               f"  {np.median(b):8.4f} {b.min():8.4f} {k2_bytes/np.median(b)/1e6:9.0f} |"
