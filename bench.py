@@ -277,7 +277,7 @@ def crossover_lp_c5():
 
 
 # the sources K1 / K2 / K10 are compiled from: their HBM traffic depends on nothing else
-WALK_SOURCES = ("sx_segwalk.h", "sx_window.h", "sx_window.hip", "sx_lp_kernels.hip", "sx_rowblock.h", "sx_rowblock.hip",
+WALK_SOURCES = ("sx_segwalk.h", "sx_runwalk.h", "sx_slabs.h", "sx_slabs.hip", "sx_window.h", "sx_window.hip", "sx_lp_kernels.hip", "sx_rowblock.h", "sx_rowblock.hip",
                 "sx_rowblock_build.hip", "sx_tiles.hip", "sx_sort.hip", "sx_internal.h")
 
 
@@ -669,7 +669,10 @@ def main():
         uniform = {"workload": "c5 with uniformly random rows (8 strata per column): no locality for the gathers",
                    "kernel": dom_u, "bound": "hbm", "achieved": ku[dom_u]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": ku[dom_u]["frac_of_hbm_peak"], "traffic": None, "kernels": ku,
-                   "row_layout": "column-blocked" if uR.rowblock() is not None else "plain walk (auto rule)"}
+                   "row_layout": "column-blocked" if uR.rowblock() is not None else "plain walk (auto rule)",
+                   "operand_slabs": {"column_walk": uC.slabs(1), "row_walk": None if uR.rowblock() is not None else uR.slabs(0),
+                                     "note": "csrc/sx_slabs.h: entries cut by operand index into L2-sized slabs, running sums "
+                                             "carried from pass to pass; bit-identical to the plain walk"}}
         for a in (uC, uR):
             a.free()
 

@@ -142,6 +142,11 @@ int sx_matrix_download_csr(const sx_matrix *A, int64_t *rowptr, int32_t *col, do
 int sx_matrix_rowblock_info(sx_ctx *ctx, const sx_matrix *A, int64_t *info);
 int sx_matrix_rowblock_download(sx_ctx *ctx, const sx_matrix *A, void *st, void *chunks, uint16_t *rowstart,
                                 int32_t *idx, double *val);
+/* Operand slabs of A's row walk (which = 0) or column walk (which = 1) under the context's "slabs" option (built now
+ * if they are due; csrc/sx_slabs.h): info[0..2] = slabs, operand indices per slab, segments; all zero when the walk
+ * is the plain one.  For tests, tools and bench.py; the walks (sx_score_columns_dev / sx_score_rows_dev /
+ * sx_price_dev, reference formats.py:70-76, net_manager.py:302-303) pick the slabs up by themselves. */
+int sx_matrix_slabs_info(sx_ctx *ctx, const sx_matrix *A, int which, int64_t *info);
 
 /* ------------------------------------------------------------------ K1: column scoring
  * replaces GeneralLP.get_dual_slack (formats.py:70-72) and the two np.where tests of

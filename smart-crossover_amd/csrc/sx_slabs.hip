@@ -196,3 +196,16 @@ int sx_slabs_get(sx_ctx *ctx, const sx_matrix *A, int which, const sx_slabs **ou
     *out = A->slabs[which];
     return SX_OK;
 }
+
+// ------------------------------------------------------------------ introspection (tests, tools, bench.py)
+SX_API int sx_matrix_slabs_info(sx_ctx *ctx, const sx_matrix *A, int which, int64_t *info /* [3] */) {
+    SX_ENTER(ctx);
+    SX_REQUIRE(A != nullptr && info != nullptr, "NULL argument");
+    SX_REQUIRE(which == 0 || which == 1, "which must be 0 (rows) or 1 (columns)");
+    const sx_slabs *S = nullptr;
+    SX_TRY(sx_slabs_get(ctx, A, which, &S));
+    info[0] = S ? S->R : 0;
+    info[1] = S ? S->width : 0;
+    info[2] = S ? S->nseg : 0;
+    return SX_OK;
+}

@@ -457,6 +457,13 @@ class DeviceMatrix:
         _l.check(self.ctx._lib.sx_matrix_download_csr(self.handle, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
         return sp.csr_matrix((val, col, rowptr), shape=(m, n))
 
+    def slabs(self, which: int):
+        """Operand slabs (csrc/sx_slabs.h) of the row walk (which = 0) or the column walk (which = 1) under the
+        context's "slabs" option, built now if due: dict(R, width, nseg), or None for the plain walk."""
+        info = (C.c_int64 * 3)()
+        _l.check(self.ctx._lib.sx_matrix_slabs_info(self.ctx.handle, self.handle, int(which), info))
+        return None if info[0] == 0 else dict(R=int(info[0]), width=int(info[1]), nseg=int(info[2]))
+
     def rowblock(self, download: bool = False):
         """Column-blocked row layout of the matrix (csrc/sx_rowblock.h) under the context's "rowblock"
         option, built now if due: a dict with the counts and, with ``download``, the arrays; None when the

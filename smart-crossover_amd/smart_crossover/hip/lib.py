@@ -89,6 +89,7 @@ PROTOTYPES = {
     "sx_matrix_arrays": (_int, [_vp] + [C.POINTER(_vp)] * 6),
     "sx_matrix_download_csr": (_int, [_vp, _vp, _vp, _vp]),
     "sx_matrix_rowblock_info": (_int, [_vp, _vp, _vp]),
+    "sx_matrix_slabs_info": (_int, [_vp, _vp, _int, _vp]),
     "sx_matrix_rowblock_download": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_score_columns_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "sx_score_columns": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp]),
