@@ -92,7 +92,7 @@ def crossover_host_path(cpu_budget_s: float):
             "index_sets_and_subproblem_match_cpu": True}
 
 
-def crossover_lp_end_to_end(highs_limit_s: float):
+def crossover_lp_end_to_end(highs_limit_s: float, cpu_path_s: float = 0.0):
     """BASELINE metric 'crossover wall-time (ms)', LP case, config 2 (2e4 x 1e5): from the interior point (x, y)
     in host memory to the optimal vertex of the perturbed sub-problem and its basis in host memory, i.e.
     get_perturb_problem + the re-solve (reference lp_methods/algorithms.py:45-61) + the gap test (:63), all on the
@@ -121,7 +121,12 @@ def crossover_lp_end_to_end(highs_limit_s: float):
     rec = {"workload": "c2: 2e4 x 1e5, 2e6 nnz; interior point -> optimal vertex + basis of the perturbed 2e4 x 2e4 "
                        "sub-problem, host memory to host memory",
            "gpu_ms": (t2 - t0) * 1e3, "gpu_get_perturb_problem_ms": (t1 - t0) * 1e3, "gpu_resolve_ms": (t2 - t1) * 1e3,
-           "simplex_pivots": int(out.iter_count), "gap_test_passed": True}
+           "simplex_pivots": int(out.iter_count), "gap_test_passed": True, "objective": float(mgr.lp_sub.c @ out.x)}
+    path = _cpu_path_record("lp_c2_cpu_path.json", {"which": "c2"}, cpu_path_s, rec["objective"], rec["gpu_ms"], rec["gpu_resolve_ms"])
+    if path is not None:
+        rec["cpu_path"] = path
+        if "speedup_total" in path:
+            rec["speedup_total"] = path["speedup_total"]
     if highs_limit_s <= 0:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "lp_c2_highs.json")), reverse=True):
@@ -178,7 +183,37 @@ def _cpu_crossover_lp(inst, highs_limit_s: float):
             "cpu_cores": os.cpu_count(), "cpu_time_limit_s": float(highs_limit_s)}
 
 
-def crossover_lp_1e6(lp_highs_s: float):
+def _cpu_path_record(name: str, which: dict, limit_s: float, objective: float, gpu_ms: float, gpu_resolve_ms: float):
+    """The CPU path that finishes, beside an LP crossover (tools/cpu_lp_path.py: numpy/scipy oracle + oracle/pdlp.py
+    first-order stage + HiGHS' simplex warm-started from the basis that point indicates -- the device's own route on
+    the host's cores; HiGHS alone does not finish on these sub-problems).  Timed in this run with ``limit_s`` > 0
+    (written to gpurun_out/<name>), otherwise the latest record committed under profiles/.  The perturbed LP has ONE
+    optimal vertex: the two objectives must agree."""
+    rec = None
+    if limit_s > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cpu_lp_path                      # (imports oracle/: checker / baseline only)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        rec = cpu_lp_path.run(dict(which, limit=limit_s, out=os.path.join(ROOT, "gpurun_out", name)))
+        rec["measured"] = "in this run, on this host"
+    else:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
+            rec = json.load(open(path))
+            rec["recorded_in"] = os.path.relpath(path, ROOT) + " (bench.py --lp-cpu-path SECONDS re-measures it)"
+            break
+    if rec is None:
+        return None
+    if rec.get("cpu_resolve_status") == "OPTIMAL":
+        if abs(rec["cpu_objective"] - objective) > 1e-7 * (1 + abs(objective)):
+            raise SystemExit(f"bench: the device's optimum ({objective!r}) differs from the CPU path's ({rec['cpu_objective']!r})")
+        rec["objective_matches_device"] = True
+        rec["speedup_total"] = rec["cpu_total_s"] * 1e3 / gpu_ms
+        rec["speedup_resolve"] = rec["cpu_resolve_s"] * 1e3 / gpu_resolve_ms
+    return rec
+
+
+def crossover_lp_1e6(lp_highs_s: float, cpu_path_s: float = 0.0):
     """BASELINE metric 'crossover wall-time (ms)' on the configuration it is quoted on: a 1e6-variable netlib-style LP
     (workloads.netlib_lp: 1e5 rows, 8e6 entries, staircase + linking rows), from the interior point (x, y) in host
     memory to the optimal vertex of the perturbed sub-problem and its basis in host memory -- get_perturb_problem
@@ -244,6 +279,12 @@ def crossover_lp_1e6(lp_highs_s: float):
         else:
             rec["speedup_total_at_least"] = cpu["cpu_total_s"] * 1e3 / rec["gpu_ms"]
         rec["target"] = ">= 5x lower crossover wall-time than the CPU path (BASELINE.json)"
+    path = _cpu_path_record("lp_1e6_cpu_path.json", {}, cpu_path_s, rec["objective"], rec["gpu_ms"], rec["gpu_resolve_ms"])
+    if path is not None:
+        rec["cpu_path"] = path
+        if "speedup_total" in path:
+            rec["speedup_total"] = path["speedup_total"]
+            rec["speedup_resolve"] = path["speedup_resolve"]
     return rec
 
 
@@ -407,6 +448,10 @@ def main():
     ap.add_argument("--lp-highs", type=float, default=0.0,
                     help="time the CPU path of the 1e6-variable LP crossover (oracle + HiGHS, this time limit in seconds) in "
                          "this run and write gpurun_out/lp_1e6_highs.json (0: quote the record under profiles/)")
+    ap.add_argument("--lp-cpu-path", type=float, default=0.0,
+                    help="time the CPU path that finishes (tools/cpu_lp_path.py: oracle + first-order stage + warm-started HiGHS "
+                         "simplex, this HiGHS time limit in seconds) beside the two LP crossovers in this run and write "
+                         "gpurun_out/lp_1e6_cpu_path.json / lp_c2_cpu_path.json (0: quote the records under profiles/)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -764,9 +809,9 @@ def main():
                 net_c4["recorded_in"] = "profiles/r02/netdual_c4_highs.jsonl (python bench.py --c4-highs re-measures it)"
                 if abs(rec["cost"] - net_c4["optimal_cost"]) > 1e-9 * (1 + abs(rec["cost"])):
                     raise SystemExit("bench: the device's config-4 optimum differs from the recorded HiGHS optimum")
-        crossover = {"lp_1e6_end_to_end": crossover_lp_1e6(args.lp_highs),
+        crossover = {"lp_1e6_end_to_end": crossover_lp_1e6(args.lp_highs, args.lp_cpu_path),
                      "lp_c2_host_path": crossover_host_path(args.cpu_seconds),
-                     "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds),
+                     "lp_c2_end_to_end": crossover_lp_end_to_end(args.highs_seconds, args.lp_cpu_path),
                      "lp_c5_get_perturb_problem": crossover_lp_c5(),
                      "network_c3": net_c3,
                      "network_mcf_4096": net_mcf,

@@ -21,8 +21,10 @@ sys.path.insert(0, ROOT)
 import workloads  # noqa: E402
 
 
-def main():
-    kw = dict(a.split("=") for a in sys.argv[1:])
+def run(kw):
+    """kw: which / m / n / iters / limit / tol / log / out as strings or numbers (see the module docstring); returns the
+    record and writes it to kw['out'] when given."""
+    kw = {k: str(v) for k, v in kw.items()}
     m, n = int(kw.get("m", 100_000)), int(kw.get("n", 1_000_000))
     iters, limit = int(kw.get("iters", 20_000)), float(kw.get("limit", 7200))
     from oracle import lp_path as L
@@ -113,10 +115,10 @@ def main():
            "cpu_resolve_status": "OPTIMAL" if status == "Optimal" else status, "highs_return": str(st),
            "cpu_resolve_iterations": int(info.simplex_iteration_count), 
            "cpu_objective": obj if status == "Optimal" else None, "cpu_cores": os.cpu_count(), "cpu_time_limit_s": limit}
-    print(json.dumps(rec), flush=True)
     if "out" in kw:
         json.dump(rec, open(kw["out"], "w"), indent=1)
+    return rec
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(dict(a.split("=") for a in sys.argv[1:]))), flush=True)
