@@ -70,9 +70,15 @@ int sx_ctx_sync(sx_ctx *ctx);
  * "rb_stage_long" (0/1, default 0: in the column-blocked row layout the products of the long rows come from a
  * column-ordered pre-pass instead of one gathered 128-byte line per entry -- bit-identical, measured slower, kept
  * as an experiment; read when a layout is built),
+ * "slabs" (operand slabs of a walk whose gathers have no locality, csrc/sx_slabs.h -- K1, K2, K10: -1 auto [default:
+ * operand beyond 3.6 MB, one slab per 3.2 MB, at least 4M entries, carries no heavier than 1.25 x the entry stream; the
+ * LDS window and the column-blocked rows are asked first], 0 never, 2..256 that many slabs; bit-identical either way --
+ * a matrix with a segment whose indices descend somewhere keeps the plain walk),
+ * "run_prefetch" (0/1, default 0: the windowed column walk with its loads one step ahead, csrc/sx_runwalk.h --
+ * bit-identical, measured 4 % slower, kept as an experiment),
  * "spx_defer" (basis inverse of sx_simplex_solve*: 0 = rank-one update after every pivot, 1 = the updates
- * of a batch of 64 pivots are kept in product form and folded in as one rank-64 update -- by rocblas_dgemm on the
- * fp64 matrix cores from 8192 rows on --, -1 auto [default]),
+ * of a batch of 64 pivots are kept in product form and folded in as one rank-64 update by a hand-written kernel,
+ * -1 auto [default]),
  * "spx_pricing" (entering variable of sx_simplex_solve*: 0 = Dantzig, largest reduced cost; 1 = Devex
  * reference weights [default], fewer pivots on general LPs, identical to Dantzig on network matrices),
  * "spx_check" (pivots between two checks of A x + s = b against the explicit inverse's drift, a multiple of 64,
