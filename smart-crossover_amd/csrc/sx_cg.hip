@@ -392,7 +392,7 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
     }
 
     const int swzT = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
-    const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64) ? 1 : 0;
+    const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64 && A->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     const int gT = grid_for(ctx, A->n_csc_tiles), gA = grid_for(ctx, A->n_csr_tiles);
     // vector kernels: grid-stride with ~4 elements per lane, at most 1024 workgroups (= partials); a
     // grid sized for the larger of m and n keeps small problems from launching mostly idle blocks
@@ -653,7 +653,7 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
     h->tol = tol;
     const int64_t m = h->m = A_loc->m, n = h->n = A_loc->n;
     h->swzT = (ctx->opt_xcd_swizzle && A_loc->n_csc_tiles >= 64) ? 1 : 0;
-    h->swzA = (ctx->opt_xcd_swizzle && A_loc->n_csr_tiles >= 64) ? 1 : 0;
+    h->swzA = (ctx->opt_xcd_swizzle && A_loc->n_csr_tiles >= 64 && A_loc->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     h->gT = grid_for(ctx, A_loc->n_csc_tiles);
     h->gA = grid_for(ctx, A_loc->n_csr_tiles);
     int64_t gv64 = ((m > n ? m : n) + 4 * SX_WG - 1) / (4 * SX_WG);
@@ -968,7 +968,7 @@ SX_API int sx_projector_free_dev(sx_ctx *ctx, const sx_matrix *A, int64_t nf, co
     } guard{A2};
     SX_TRY(sx_gather_f64_dev(ctx, nf, free_idx, c, c_free));
     const int swzT = (ctx->opt_xcd_swizzle && A2->n_csc_tiles >= 64) ? 1 : 0;
-    const int swzA = (ctx->opt_xcd_swizzle && A2->n_csr_tiles >= 64) ? 1 : 0;
+    const int swzA = (ctx->opt_xcd_swizzle && A2->n_csr_tiles >= 64 && A2->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     const int gT = grid_for(ctx, A2->n_csc_tiles), gA = grid_for(ctx, A2->n_csr_tiles);
     const dim3 gv = g1(nf);
     hipLaunchKernelGGL(k_cg_ones, gv, dim3(SX_WG), 0, s, nf, ones);

@@ -365,8 +365,8 @@ SX_API int sx_gather_columns_dev(sx_ctx *ctx, const sx_matrix *A, const int64_t 
             rc = SX_ERR_HIP;
             break;
         }
-        if ((rc = sx_build_tiles(ctx, S->csr_ptr, m, &S->csr_tiles, &S->n_csr_tiles)) != SX_OK) break;
-        if ((rc = sx_build_tiles(ctx, S->csc_ptr, nsub, &S->csc_tiles, &S->n_csc_tiles)) != SX_OK) break;
+        if ((rc = sx_build_tiles(ctx, S->csr_ptr, m, &S->csr_tiles, &S->n_csr_tiles, &S->csr_imbalance)) != SX_OK) break;
+        if ((rc = sx_build_tiles(ctx, S->csc_ptr, nsub, &S->csc_tiles, &S->n_csc_tiles, &S->csc_imbalance)) != SX_OK) break;
         if (hipStreamSynchronize(s) != hipSuccess) {
             sx_set_error("stream sync failed after compaction");
             rc = SX_ERR_HIP;

@@ -391,8 +391,8 @@ SX_API int sx_matrix_create(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz,
             rc = SX_ERR_HIP;
         }
     }
-    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles);
-    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles);
+    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles, &A->csr_imbalance);
+    if (rc == SX_OK) rc = sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles, &A->csc_imbalance);
     if (rc != SX_OK) {
         sx_matrix_destroy(A);
         return rc;
@@ -436,8 +436,8 @@ SX_API int sx_matrix_create_single(sx_ctx *ctx, int64_t m, int64_t n, int64_t nn
         rc = check_layout_dev(ctx, is_csc ? A->csc_ptr : A->csr_ptr, nseg, is_csc ? A->csc_idx : A->csr_idx, idx, nnz,
                               bound, is_csc ? "colptr" : "rowptr", is_csc ? "row index" : "column index");
     if (rc == SX_OK)
-        rc = is_csc ? sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles)
-                    : sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles);
+        rc = is_csc ? sx_build_tiles(ctx, A->csc_ptr, n, &A->csc_tiles, &A->n_csc_tiles, &A->csc_imbalance)
+                    : sx_build_tiles(ctx, A->csr_ptr, m, &A->csr_tiles, &A->n_csr_tiles, &A->csr_imbalance);
     if (rc != SX_OK) {
         sx_matrix_destroy(A);
         return rc;

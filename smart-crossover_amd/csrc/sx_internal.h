@@ -142,6 +142,7 @@ struct sx_matrix {
     int64_t n_csr_tiles = 0;
     int64_t *csc_tiles = nullptr;
     int64_t n_csc_tiles = 0;
+    double csr_imbalance = 1.0, csc_imbalance = 1.0; // of the XCD-contiguous tile ranges (sx_build_tiles)
     // optional per-tile operand window of the column walk (sx_window.hip), built on first use
     mutable int32_t *csc_win_lo = nullptr;
     mutable int csc_win_tried = 0;
@@ -163,8 +164,13 @@ int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out);
 int sx_transpose_dev(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int32_t *col,
                      const double *val, int64_t **colptr_out, int32_t **row_out, double **val_out);
 
+// *imbalance_out (optional): serial cost of the heaviest of the eight XCD-contiguous tile ranges over the mean, a
+// tile costing its average segment length (the adds a lane makes one after another) + 64
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
-                   int64_t *ntiles_out);
+                   int64_t *ntiles_out, double *imbalance_out = nullptr);
+// the XCD-contiguous tile map (speed only) is used for a walk unless its ranges are that uneven: long segments that
+// sit together -- the linking rows at the head of an LP -- would all queue on one XCD
+constexpr double SX_SWIZZLE_MAX_IMBALANCE = 1.5;
 // exclusive scan of in[0..n) into out[0..n] (out[n] = total); uses ctx->ws (sx_compact.hip)
 int sx_scan_exclusive(sx_ctx *ctx, const int64_t *in, int64_t n, int64_t *out);
 

@@ -674,10 +674,12 @@ SX_API int sx_score_rows_dev(sx_ctx *ctx, const sx_matrix *A, const double *x, c
             return SX_OK;
         }
     }
-    const unsigned grid = walk_grid(ctx, A->n_csr_tiles);
+    // (linking rows that sit together would all queue on one XCD under the contiguous map: sx_build_tiles)
+    const int swz2 = (ctx->opt_xcd_swizzle && A->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
+    const unsigned grid = swz2 ? walk_grid(ctx, A->n_csr_tiles) : static_cast<unsigned>(A->n_csr_tiles);
 #define SX_LAUNCH_K2(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_rows<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,           \
-                       A->csr_tiles, A->n_csr_tiles, ctx->opt_xcd_swizzle, A->csr_ptr, A->csr_idx, \
+                       A->csr_tiles, A->n_csr_tiles, swz2, A->csr_ptr, A->csr_idx,                 \
                        A->csr_val, x, b, y, gamma_dual, s_p, flag, static_cast<const double *>(nullptr))
     SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K2);
 #undef SX_LAUNCH_K2

@@ -20,6 +20,17 @@ __global__ __launch_bounds__(SX_WG) void k_tile_flags(const int64_t *__restrict_
     flag[s] = cut ? 1 : 0;
 }
 
+// serial cost of the eight XCD-contiguous tile ranges (the map of sx_tile_of_block): cost[k] += avg segment length + 64
+__global__ __launch_bounds__(SX_WG) void k_tile_range_cost(const int64_t *__restrict__ tiles, int64_t ntiles,
+                                                           const int64_t *__restrict__ ptr, unsigned long long *__restrict__ cost) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
+    if (t >= ntiles) return;
+    const int64_t s0 = tiles[t], s1 = tiles[t + 1];
+    const int64_t per = (ntiles + 7) >> 3;
+    const int64_t segs = s1 > s0 ? s1 - s0 : 1;
+    atomicAdd(&cost[t / per], static_cast<unsigned long long>((ptr[s1] - ptr[s0]) / segs + 64));
+}
+
 // Entry budget of a tile: SX_TILE_BUDGET for large matrices; halved (down to 1024) while the matrix
 // would otherwise yield fewer than ~2048 tiles, so that cache-resident problems still put several
 // workgroups on each of the 256 CUs (config 2: 250 row tiles -> 2000).
@@ -32,9 +43,10 @@ inline int64_t tile_budget(int64_t nnz) {
 } // namespace
 
 int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **tiles_out,
-                   int64_t *ntiles_out) {
+                   int64_t *ntiles_out, double *imbalance_out) {
     *tiles_out = nullptr;
     *ntiles_out = 0;
+    if (imbalance_out) *imbalance_out = 1.0;
     int64_t *tiles = nullptr;
     if (nseg == 0) {
         SX_HIP(hipMalloc(reinterpret_cast<void **>(&tiles), sizeof(int64_t)));
@@ -80,6 +92,23 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
             sx_set_error("tile table copy failed");
             rc = SX_ERR_HIP;
+        }
+    }
+    if (rc == SX_OK && imbalance_out && nt >= 64) { // (reuses `idx`: 8 counters)
+        unsigned long long cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(idx);
+        if (hipMemsetAsync(d, 0, sizeof(cost), ctx->stream) == hipSuccess) {
+            hipLaunchKernelGGL(k_tile_range_cost, dim3(static_cast<unsigned>((nt + SX_WG - 1) / SX_WG)), dim3(SX_WG), 0, ctx->stream,
+                               tiles, nt, ptr_dev, d);
+            if (hipMemcpyAsync(cost, d, sizeof(cost), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                double sum = 0.0, mx = 0.0;
+                for (unsigned long long c : cost) {
+                    sum += static_cast<double>(c);
+                    mx = mx > static_cast<double>(c) ? mx : static_cast<double>(c);
+                }
+                if (sum > 0.0) *imbalance_out = mx / (sum / 8.0);
+            }
         }
     }
     if (flag) (void)hipFree(flag);
