@@ -122,3 +122,28 @@ def test_automatic_rule_at_config5_rows_uniform(ctx):
         dC.free()
     ctx.set_option("slabs", -1)
     assert bits_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("head", [True, False])
+def test_row_walk_with_linking_rows_at_the_head_or_spread(ctx, head):
+    """The XCD-contiguous tile map of the plain row walk is dropped when the long rows sit together (sx_build_tiles'
+    imbalance figure: they would all queue on one XCD) -- a scheduling decision that must not show in the sums."""
+    rng = np.random.default_rng(7)
+    m, n, k = 40_000, 60_000, 6
+    rows = rng.integers(0, m, size=n * k)
+    cols = np.repeat(np.arange(n), k)
+    long_rows = np.arange(200) if head else rng.choice(m, 200, replace=False)
+    lr = np.repeat(long_rows, 3_000)
+    lc = rng.integers(0, n, size=lr.size)
+    A = sp.csr_matrix((rng.standard_normal(rows.size + lr.size), (np.r_[rows, lr], np.r_[cols, lc])), shape=(m, n))
+    x, y, b = rng.random(n), rng.standard_normal(m), rng.standard_normal(m)
+    ctx.set_option("rowblock", 0)
+    ctx.set_option("slabs", 0)
+    dA = ctx.row_shard(A)
+    s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
+    ctx.score_rows(dA, ctx.to_device(x), ctx.to_device(b), ctx.to_device(y), 1e-3, s_p, flag)
+    got = s_p.download()
+    dA.free()
+    ctx.set_option("rowblock", -1)
+    ctx.set_option("slabs", -1)
+    assert bits_equal(got, L.primal_slack(A, b, x))
