@@ -798,6 +798,9 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     {   // no locality and an operand beyond L2: slab after slab (sx_slabs.h), pricing in the last pass
         const sx_slabs *S = nullptr;
         SX_TRY(sx_slabs_get(ctx, A, 1, &S));
+        // (a first call builds the slabs with scans in the context's workspace, which may have moved it)
+        SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb > 0 ? nb : 1) * sizeof(PricePartial)));
+        partial = static_cast<PricePartial *>(ctx->ws);
         if (S) {
             SX_TRY(slab_passes(ctx, S, y));
             const sx_slab &L = S->slab[S->R - 1];
@@ -805,6 +808,8 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
             int nbl = static_cast<int>(L.ntiles < PRICE_GRID ? L.ntiles : PRICE_GRID);
             if (swl) nbl &= ~7;
             if (nbl < 1) nbl = 1;
+            SX_TRY(sx_reserve(ctx, static_cast<size_t>(nbl) * sizeof(PricePartial)));
+            partial = static_cast<PricePartial *>(ctx->ws);
             hipLaunchKernelGGL((k_price<4096, 2>), dim3(nbl), dim3(SX_WG), 0, ctx->stream, L.tiles, L.ntiles, swl, L.ptr, L.idx,
                                L.val, y + L.off, c, vbasis, tol, rc, partial, S->carry);
             hipLaunchKernelGGL(k_price_final, dim3(1), dim3(SX_WG), 0, ctx->stream, partial, static_cast<int64_t>(nbl), result_dev);

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(SX_WG) void k_slab_count(int64_t nseg, const int64_
         const int32_t i = idx[e];
         if (i < prev) *descending = 1; // benign race: every writer stores 1
         prev = i;
-        const int si = static_cast<int>(i / width);
+        int si = static_cast<int>(i / width);
+        si = si < R ? si : R - 1; // (an index beyond the operand: the walk would fault on it as well; keep the table whole)
         if (si != s) {
             if (si > s) { // (si < s only on a descending segment: refused anyway)
                 cnt[static_cast<int64_t>(s) * nseg + j] = run;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(SX_WG) void k_slab_count(int64_t nseg, const int64_
 
 // one lane per segment: its entries to their slabs, stored order kept
 __global__ __launch_bounds__(SX_WG) void k_slab_scatter(int64_t nseg, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                                        const double *__restrict__ val, int64_t width,
+                                                        const double *__restrict__ val, int64_t width, int R,
                                                         const SlabDev *__restrict__ slabs) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * SX_WG + threadIdx.x;
     if (j >= nseg) return;
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(SX_WG) void k_slab_scatter(int64_t nseg, const int6
     SlabDev d{nullptr, nullptr, nullptr};
     for (int64_t e = e0; e < e1; ++e) {
         const int32_t i = idx[e];
-        const int si = static_cast<int>(i / width);
+        int si = static_cast<int>(i / width);
+        si = si < R ? si : R - 1;
         if (si != s) {
             s = si;
             d = slabs[s];
@@ -131,7 +133,7 @@ int build(sx_ctx *ctx, const int64_t *ptr, const int32_t *idx, const double *val
         host[static_cast<size_t>(s)] = SlabDev{L.ptr, L.idx, L.val};
     }
     SX_HIP(hipMemcpyAsync(dev, host.data(), sizeof(SlabDev) * static_cast<size_t>(R), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_slab_scatter, dim3(grid1d(nseg)), dim3(SX_WG), 0, st, nseg, ptr, idx, val, width, dev);
+    hipLaunchKernelGGL(k_slab_scatter, dim3(grid1d(nseg)), dim3(SX_WG), 0, st, nseg, ptr, idx, val, width, R, dev);
     SX_HIP(hipGetLastError());
     SX_HIP(hipStreamSynchronize(st)); // `host` leaves scope
     int64_t total = 0;
