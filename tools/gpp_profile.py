@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Where the time of get_perturb_problem goes when it follows a re-solve (bench.py's order): [gpp, resolve] x 2 on the
+headline LP, host-side profile of the second gpp.  Development tool."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
+import workloads  # noqa: E402
+from smart_crossover.formats import GeneralLP  # noqa: E402
+from smart_crossover.lp_methods import algorithms as alg  # noqa: E402
+from smart_crossover.solver_caller.caller import SolverSettings  # noqa: E402
+from smart_crossover.solver_caller import solving  # noqa: E402
+
+inst = workloads.netlib_lp()
+for rep in range(3):
+    lp = GeneralLP(inst.A, inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        pr.enable()
+        mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+        pr.disable()
+    t1 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        caller = solving.generate_solver_caller("HIP", SolverSettings(presolve="on", log_console=0))
+        caller.read_genlp(mgr.lp_sub)
+        caller.add_warm_start_solution((mgr.get_subx(inst.x), inst.y))
+        caller.run_barrier()
+        out = caller.return_output()
+    t2 = time.perf_counter()
+    print(f"rep {rep}: get_perturb_problem {1e3 * (t1 - t0):.1f} ms, resolve {1e3 * (t2 - t1):.1f} ms", flush=True)
+    if rep == 2:
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14)
+        print(s.getvalue())
