@@ -72,6 +72,7 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
     if (ctx->nd_order) (void)hipFree(ctx->nd_order);
     if (ctx->nd_y) (void)hipFree(ctx->nd_y);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->t_made)
         for (int i = 0; i < 8; ++i) {
             (void)hipEventDestroy(ctx->t0[i]);
@@ -212,6 +213,33 @@ SX_API int sx_download(sx_ctx *ctx, void *dst_host, const void *src_dev, size_t 
     SX_ENTER(ctx);
     if (bytes == 0) return SX_OK;
     SX_REQUIRE(dst_host && src_dev, "NULL pointer in sx_download");
+    constexpr size_t HALF = static_cast<size_t>(8) << 20; // 8 MiB per half
+    if (bytes >= (static_cast<size_t>(64) << 10)) {
+        if (!ctx->pin && hipHostMalloc(&ctx->pin, 2 * HALF, hipHostMallocDefault) == hipSuccess) ctx->pin_half = HALF;
+        if (ctx->pin) { // piece k + 1 is on its way while piece k is copied out
+            char *dst = static_cast<char *>(dst_host);
+            const char *src = static_cast<const char *>(src_dev);
+            char *half[2] = {static_cast<char *>(ctx->pin), static_cast<char *>(ctx->pin) + ctx->pin_half};
+            size_t off = 0, n_cur = bytes < ctx->pin_half ? bytes : ctx->pin_half;
+            int cur = 0;
+            SX_HIP(hipMemcpyAsync(half[0], src, n_cur, hipMemcpyDeviceToHost, ctx->stream));
+            while (off < bytes) {
+                SX_HIP(hipStreamSynchronize(ctx->stream));
+                const size_t next_off = off + n_cur;
+                size_t n_next = 0;
+                if (next_off < bytes) {
+                    n_next = bytes - next_off < ctx->pin_half ? bytes - next_off : ctx->pin_half;
+                    SX_HIP(hipMemcpyAsync(half[cur ^ 1], src + next_off, n_next, hipMemcpyDeviceToHost, ctx->stream));
+                }
+                memcpy(dst + off, half[cur], n_cur);
+                off = next_off;
+                n_cur = n_next;
+                cur ^= 1;
+            }
+            return SX_OK;
+        }
+        (void)hipGetLastError(); // no pinned memory to be had: the plain copy below
+    }
     SX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SX_HIP(hipStreamSynchronize(ctx->stream));
     return SX_OK;

@@ -67,6 +67,11 @@ struct sx_ctx {
     double *nd_y = nullptr;       // [V] potentials
     int64_t nd_tree_V = 0;
     int nd_tree_root = -1;
+    // pinned staging of sx_download (two halves, used alternately): a device-to-host copy into never-touched pageable
+    // memory -- a fresh numpy array -- faults its pages inside the driver (3 ms per 8 MB measured in a process with a
+    // large heap); into pinned memory it runs at link speed and the memcpy out of it at memory speed
+    void *pin = nullptr;
+    size_t pin_half = 0;
     // timers
     hipEvent_t t0[8];
     hipEvent_t t1[8];

@@ -18,6 +18,20 @@ from smart_crossover.lp_methods import algorithms as alg  # noqa: E402
 from smart_crossover.solver_caller.caller import SolverSettings  # noqa: E402
 from smart_crossover.solver_caller import solving  # noqa: E402
 
+keep = []
+if "prelude" in sys.argv:   # bench.py's state: a second context with the config-5 shards resident and one scoring step done
+    import numpy as np
+    from smart_crossover.hip import Context
+    sh = workloads.lp_shard(0, 1)
+    c5 = Context(0)
+    dC, dR = c5.column_shard(sh.col_block), c5.row_shard(sh.row_block)
+    d = {k: c5.to_device(getattr(sh, k)) for k in ("y", "x", "c", "l", "u", "b")}
+    s_d, code = c5.empty(sh.col_block.shape[1], np.float64), c5.empty(sh.col_block.shape[1], np.uint8)
+    c5.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)
+    c5.sync()
+    keep = [sh, c5, dC, dR, d, s_d, code]
+    if "free" in sys.argv:
+        dC.free(); dR.free()
 inst = workloads.netlib_lp()
 for rep in range(3):
     lp = GeneralLP(inst.A, inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
