@@ -210,6 +210,8 @@ def _cpu_path_record(name: str, which: dict, limit_s: float, objective: float, g
         rec["device_objective"] = objective
         rec["speedup_total"] = rec["cpu_total_s"] * 1e3 / gpu_ms
         rec["speedup_resolve"] = rec["cpu_resolve_s"] * 1e3 / gpu_resolve_ms
+    elif rec.get("cpu_total_s"):   # stopped without a solution: a lower bound, named as such
+        rec["speedup_total_at_least"] = rec["cpu_total_s"] * 1e3 / gpu_ms
     return rec
 
 
