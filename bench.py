@@ -235,9 +235,19 @@ def crossover_lp_1e6(lp_highs_s: float, cpu_path_s: float = 0.0):
     runs = []
     for rep in range(3):
         lp = GeneralLP(inst.A, inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
+        prof = None
+        if rep == 2 and os.environ.get("SX_BENCH_GPP_PROFILE"):   # development: where get_perturb_problem's time goes here
+            import cProfile
+            prof = cProfile.Profile()
         t0 = time.perf_counter()
         with redirect_stdout(io.StringIO()):
+            if prof:
+                prof.enable()
             mgr = alg.get_perturb_problem(lp, inst.x, inst.y, 1e-3, 1e-3, False)
+            if prof:
+                prof.disable()
+                import pstats
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
             t1 = time.perf_counter()
             caller = solving.generate_solver_caller("HIP", SolverSettings(presolve="on", log_console=0))
             caller.read_genlp(mgr.lp_sub)
