@@ -19,6 +19,12 @@ from smart_crossover.solver_caller.caller import SolverSettings  # noqa: E402
 from smart_crossover.solver_caller import solving  # noqa: E402
 
 keep = []
+if "torch" in sys.argv:     # bench.py brings torch's HIP runtime up first (sharded CG / pricing legs)
+    import torch
+    torch.cuda.set_device(0)
+    keep.append(torch.cuda.Stream())
+if "dist" in sys.argv:      # ... and imports the sharded driver
+    from smart_crossover import distributed  # noqa: F401
 if "prelude" in sys.argv:   # bench.py's state: a second context with the config-5 shards resident and one scoring step done
     import numpy as np
     from smart_crossover.hip import Context
@@ -30,6 +36,22 @@ if "prelude" in sys.argv:   # bench.py's state: a second context with the config
     c5.score_columns(dC, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)
     c5.sync()
     keep = [sh, c5, dC, dR, d, s_d, code]
+    if "k2" in sys.argv:     # the row walk too: its first call builds the column-blocked layout (GBs of sort temporaries)
+        s_p, flag = c5.empty(sh.row_block.shape[0], np.float64), c5.empty(sh.row_block.shape[0], np.uint8)
+        c5.score_rows(dR, d["x"], d["b"], d["y"], 1e-3, s_p, flag)
+        c5.sync()
+        keep += [s_p, flag]
+    if "k10" in sys.argv:    # pricing rounds
+        vb = c5.to_device(np.where(np.arange(sh.col_block.shape[1]) % 7 == 0, -2, -1).astype(np.int8))
+        res = None
+        for _ in range(50):
+            res = c5.price(dC, d["y"], d["c"], vb, 1e-6, None, res)
+        c5.sync()
+        keep += [vb, res]
+    if "oracle" in sys.argv: # the numpy / scipy baseline leg
+        from oracle import lp_path as L
+        for _ in range(3):
+            L.scoring_pass(sh.row_block, sh.b, sh.c, sh.l, sh.u, sh.x, sh.y[:sh.row_block.shape[0]])
     if "load" in sys.argv:   # half a minute of the scoring walks first, as bench.py's timed and profiled loops do
         t_end = time.perf_counter() + 30.0
         while time.perf_counter() < t_end:
