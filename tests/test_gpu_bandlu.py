@@ -93,7 +93,7 @@ def test_columns_without_a_pivot_are_replaced_and_reported(ctx):
     assert set(np.flatnonzero(rep)) >= set(dead) and rep.sum() == len(dead) + 1
     assert rep[99] + rep[100] == 1
     B = with_replaced_columns(A, rep, piv).toarray()
-    assert abs(np.linalg.det(B / np.abs(B).max())) > 0 or True
+    assert np.linalg.matrix_rank(B) == n and np.linalg.cond(B) < 1e10   # the repaired matrix is what was factored: non-singular
     rng = np.random.default_rng(3)
     R = rng.standard_normal((n, 9))
     for trans in (False, True):
