@@ -464,6 +464,24 @@ int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_
 int sx_bandlu_solve_sparse_dev(sx_bandlu *h, int64_t nrhs, double *X, int64_t ldx, double tiny);
 int sx_bandlu_destroy(sx_bandlu *h);
 
+/* ------------------------------------------------------------------ K16g: dense LU of a Schur complement
+ * Companion of K16f for the BORDER of a bordered band basis (csrc/sx_border.hip): the linking rows of a staged LP, the rows
+ * the band matching leaves over and the separators between the band's blocks form a dense Schur complement of a few
+ * thousand rows -- factored here (csrc/sx_denselu.hip) the way the reference's solvers factor whatever basis they meet
+ * (solver_caller/gurobi.py:202-210 model.optimize()).  n x n, n <= 16384, column major on the device.  factor: partial
+ * pivoting, right-looking, panels of 8 inside blocks of 64, trailing updates on the fp64 matrix cores; a column whose
+ * largest candidate pivot is <= pivot_tol is REPLACED by the unit vector of the row on its diagonal and reported
+ * (replaced_host[n]; rowperm_host[n]: the original row that ended at position i -- a replaced column j stands for the unit
+ * vector of row rowperm_host[j]).  solve: nrhs right-hand sides, column major with leading dimension ldx, in place; trans 0:
+ * A x = b, 1: A^T x = b (A = the matrix with its replaced columns).  Blocking (factor) / stream-ordered (set, solve). */
+typedef struct sx_denselu sx_denselu;
+int sx_denselu_create_dev(sx_ctx *ctx, int64_t n, sx_denselu **out);
+int sx_denselu_set_dev(sx_denselu *h, const double *src, int64_t lds);
+int sx_denselu_factor_dev(sx_denselu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
+                          int32_t *rowperm_host);
+int sx_denselu_solve_dev(sx_denselu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
+int sx_denselu_destroy(sx_denselu *h);
+
 /* Sparse crossover (K16s, csrc/sx_crossover_band.hip): the same job as sx_simplex_crossover_dev -- from the point
  * x_start[n] (what sx_pdlp_dev leaves: columns at a bound exactly where the projection put them) to an optimal
  * vertex and its basis -- without the dense m x m inverse: the starting basis is chosen by position (rows in their

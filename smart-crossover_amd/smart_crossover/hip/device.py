@@ -361,6 +361,32 @@ class BandLU:
             self.handle = None
 
 
+class DenseLU:
+    """K16g: dense LU with partial pivoting of an n x n column-major device matrix (sx_denselu_*)."""
+
+    def __init__(self, ctx: "Context", n: int, a: "DeviceArray", lda: Optional[int] = None):
+        self.ctx, self.n = ctx, int(n)
+        h = C.c_void_p()
+        _l.check(ctx._lib.sx_denselu_create_dev(ctx.handle, int(n), C.byref(h)))
+        self.handle = h
+        _l.check(ctx._lib.sx_denselu_set_dev(h, a.ptr, int(lda or n)))
+
+    def factor(self, pivot_tol: float = 1e-11):
+        """-> (replaced[n] int32, rowperm[n] int32: original row at position i after the swaps)."""
+        cnt = C.c_int64(0)
+        rep, perm = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        _l.check(self.ctx._lib.sx_denselu_factor_dev(self.handle, float(pivot_tol), C.byref(cnt), rep.ctypes.data, perm.ctypes.data))
+        return rep, perm
+
+    def solve(self, X: "DeviceArray", nrhs: int = 1, ldx: Optional[int] = None, trans: bool = False) -> None:
+        _l.check(self.ctx._lib.sx_denselu_solve_dev(self.handle, int(bool(trans)), int(nrhs), X.ptr, int(ldx or self.n)))
+
+    def free(self) -> None:
+        if self.handle is not None:
+            self.ctx._lib.sx_denselu_destroy(self.handle)
+            self.handle = None
+
+
 class DeviceArray:
     """A typed, contiguous vector in HBM."""
 

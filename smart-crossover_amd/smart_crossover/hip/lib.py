@@ -138,6 +138,11 @@ PROTOTYPES = {
     "sx_bandlu_solve_dev": (_int, [_vp, _int, _i64, _vp, _i64]),
     "sx_bandlu_solve_sparse_dev": (_int, [_vp, _i64, _vp, _i64, _dbl]),
     "sx_bandlu_destroy": (_int, [_vp]),
+    "sx_denselu_create_dev": (_int, [_vp, _i64, C.POINTER(_vp)]),
+    "sx_denselu_set_dev": (_int, [_vp, _vp, _i64]),
+    "sx_denselu_factor_dev": (_int, [_vp, _dbl, C.POINTER(_i64), _vp, _vp]),
+    "sx_denselu_solve_dev": (_int, [_vp, _int, _i64, _vp, _i64]),
+    "sx_denselu_destroy": (_int, [_vp]),
     "sx_netsimplex_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  C.POINTER(SimplexResult)]),
     "sx_netdual_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp,
