@@ -453,19 +453,26 @@ int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *
  * matrix with its replaced columns).  solve_sparse: A x = b for right-hand sides with few entries each (the columns
  * of an LP): panels of 32 rows whose entries are all <= tiny in magnitude are skipped, in the forward sweep (before the
  * first entry of b, and once the fill past its last entry has decayed below tiny) and in the backward sweep; tiny = 0
- * skips exact zeros only and returns the plain solve's result.  Limits: kl + 32 <= 1536, kl + ku + 32 <= 2400.
+ * skips exact zeros only and returns the result of the plain solve's sequential sweeps (solve takes partitioned sweeps --
+ * blocks of panels side by side, rounding differently -- for up to 1,024 right-hand sides unless SX_BANDLU_SEQ is set).  Limits: kl + 32 <= 1536, kl + ku + 32 <= 1980.
  * Blocking (factor) / stream-ordered (solve); arrays device unless named host. */
 typedef struct sx_bandlu sx_bandlu;
 int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
                          const double *val, sx_bandlu **out);
 int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
                          int32_t *ipiv_host);
+/* factor_blocks: the same for a matrix that is block diagonal with identity padding between its blocks -- block b holds the
+ * columns and rows [b stride, b stride + real_len) (real_len_last for the last of nblocks), identity up to the next
+ * block, stride >= real_len + kl + ku + 32, no entry coupling two blocks: the blocks' panels are factored side by side
+ * (the sparse crossover cuts its band at separators that go to the border; csrc/sx_crossover_band.hip). */
+int sx_bandlu_factor_blocks_dev(sx_bandlu *h, double pivot_tol, int nblocks, int64_t stride, int64_t real_len,
+                                int64_t real_len_last, int64_t *n_replaced_out, int32_t *replaced_host, int32_t *ipiv_host);
 int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
 int sx_bandlu_solve_sparse_dev(sx_bandlu *h, int64_t nrhs, double *X, int64_t ldx, double tiny);
 int sx_bandlu_destroy(sx_bandlu *h);
 
 /* ------------------------------------------------------------------ K16g: dense LU of a Schur complement
- * Companion of K16f for the BORDER of a bordered band basis (csrc/sx_border.hip): the linking rows of a staged LP, the rows
+ * Companion of K16f for the BORDER of a bordered band basis (csrc/sx_border.h, sx_border.hip): the linking rows of a staged LP, the rows
  * the band matching leaves over and the separators between the band's blocks form a dense Schur complement of a few
  * thousand rows -- factored here (csrc/sx_denselu.hip) the way the reference's solvers factor whatever basis they meet
  * (solver_caller/gurobi.py:202-210 model.optimize()).  n x n, n <= 16384, column major on the device.  factor: partial
@@ -482,20 +489,36 @@ int sx_denselu_factor_dev(sx_denselu *h, double pivot_tol, int64_t *n_replaced_o
 int sx_denselu_solve_dev(sx_denselu *h, int trans, int64_t nrhs, double *X, int64_t ldx);
 int sx_denselu_destroy(sx_denselu *h);
 
-/* Sparse crossover (K16s, csrc/sx_crossover_band.hip): the same job as sx_simplex_crossover_dev -- from the point
- * x_start[n] (what sx_pdlp_dev leaves: columns at a bound exactly where the projection put them) to an optimal
- * vertex and its basis -- without the dense m x m inverse: the starting basis is chosen by position (rows in their
- * natural order, dense rows covered by their logicals), its band part factored once (K16f), and the simplex works
- * on an explicit tableau of the columns that can still move (superbasic ones + what pricing adds), every entering
- * column kept as an eta vector for duals and new columns.  Memory O(nnz + m (kl + ku) + m |tracked|).  Replaces
- * the crossover the reference's backends run behind their barrier (lp_methods/algorithms.py:50-54 ->
- * solver_caller/gurobi.py:111-115).  Returns SX_ERR_UNSUPPORTED when the basis is not a band matrix in the natural
- * row order (the caller then takes sx_simplex_crossover_dev).  Outputs and result as sx_simplex_crossover_dev;
- * result->phase1_iters counts the columns pricing added to the tableau.  Blocking; arrays device. */
+/* Sparse crossover (K16s, csrc/sx_crossover_band.hip + csrc/sx_border.hip): the same job as sx_simplex_crossover_dev --
+ * from the point x_start[n] (what sx_pdlp_dev leaves: columns at a bound exactly where the projection put them) to an
+ * optimal vertex and its basis -- without the dense m x m inverse.  The basis is factored in BORDERED form: rows in their
+ * natural (or Cuthill-McKee) order, rows with more than max(24, 6 x average) entries ("dense", the linking rows) set aside;
+ * the basic variables matched to the band rows by entry size form a band matrix (K16f), the others (linking activities,
+ * logicals of dense rows, what the band LU set aside) the border, whose Schur complement goes to the dense LU (K16g).
+ * Every basic variable is in the factors: a fresh factorisation (full eta file, numerical trouble, the final check of the
+ * vertex against A) is a true refactorisation.  The simplex works on an explicit tableau of the columns that can still
+ * move (superbasic ones + what pricing adds; grown on demand), every entering column kept as an eta vector for duals and
+ * new columns.  Memory O(nnz + m (kl + ku) + border^2 + m |tracked|).  Replaces the crossover the reference's backends run
+ * behind their barrier (lp_methods/algorithms.py:50-54 -> solver_caller/gurobi.py:111-115).
+ *   sx_crossover_band_dev        the starting basis is guessed from x_start: the m variables with the largest margins;
+ *   sx_crossover_band_basis_dev  the starting basis is GIVEN (vbasis_in[n], cbasis_in[m]: 0 basic, -1 / -2 non-basic at
+ *                                its lower / upper bound, -3 superbasic at x_start; codes of smart_crossover/output.py) --
+ *                                the reference's warm-started final solve (lp_methods/algorithms.py:69-74,
+ *                                lp_manager.py:79-89); a basis with too few / too many members is completed by logicals /
+ *                                thinned to superbasic columns; both NULL = sx_crossover_band_dev.
+ * Return SX_ERR_UNSUPPORTED when the matched basis is no band matrix the band LU takes (kl + 32 <= 1536 and
+ * kl + ku + 32 <= 1980) or its border passes 16,384 rows (the caller then takes sx_simplex_crossover_dev).  Outputs and
+ * result as sx_simplex_crossover_dev; result->phase1_iters counts the columns pricing added to the tableau,
+ * result->max_violation covers bound violations of the basic variables AND the relative row residual of x.  Status 0 is
+ * only returned for a vertex whose row residuals and basic reduced costs passed the check against A.  Blocking; arrays device. */
 int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
                           const double *u, const uint8_t *row_is_lt, const double *x_start, int64_t max_iter,
                           double feas_tol, double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
                           sx_simplex_result *result);
+int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
+                                const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x,
+                                double *y, int8_t *vbasis, int8_t *cbasis, sx_simplex_result *result);
 
 /* Network simplex (K16n) for the re-solves of the network crossover (network_methods/net_manager.py:211-222
  * solve_subproblem -> solve_mcf / solve_ot with warm_start_basis; the reference hands these to Gurobi's /

@@ -44,11 +44,20 @@ struct sx_bandlu {
     int part_LBp = 0, part_P = 0;
     double *part_R[4] = {nullptr, nullptr, nullptr, nullptr};
     double *part_buf = nullptr, *part_delta = nullptr;
+    int part_cols = 0; // right-hand sides part_buf / part_delta hold (grown on demand: gb_part_reserve)
 };
 
 namespace {
 
 constexpr int GB_NB = 32; // panel width
+// Independent diagonal blocks factored side by side (sx_bandlu_factor_blocks_dev): block b holds the columns
+// [b stride, b stride + len_b), len_b = rl (rl_last for the last block), followed by identity padding up to the next block
+struct GbBlocks {
+    int nblk;
+    int64_t stride, rl, rl_last;
+    __host__ __device__ int64_t base(int b) const { return static_cast<int64_t>(b) * stride; }
+    __host__ __device__ int64_t len(int b) const { return b == nblk - 1 ? rl_last : rl; }
+};
 constexpr int GB_CB = 8;  // target columns per workgroup of the apply / solve kernels
 constexpr int GB_T2 = 256;
 
@@ -224,11 +233,14 @@ struct GbPanelSteps<T, RPT, GB_NB> {
 };
 
 template <int T, int RPT>
-__global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0,
-                                                int ncol, double tol, int32_t *__restrict__ ipiv,
-                                                int32_t *__restrict__ replaced) {
+__global__ __launch_bounds__(T) void k_gb_panel(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0_rel,
+                                                double tol, int32_t *__restrict__ ipiv, int32_t *__restrict__ replaced, GbBlocks B) {
     __shared__ GbPanelShared<T, RPT> sh;
     const int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    if (j0_rel >= B.len(blk)) return; // (uniform: this block has no panel at this step)
+    const int64_t j0 = B.base(blk) + j0_rel;
+    const int ncol = static_cast<int>((B.len(blk) - j0_rel < GB_NB) ? B.len(blk) - j0_rel : GB_NB);
     const int64_t R64 = (n - j0 < static_cast<int64_t>(kl) + ncol) ? n - j0 : static_cast<int64_t>(kl) + ncol;
     const int R = static_cast<int>(R64);
     double v[RPT][GB_NB];
@@ -736,15 +748,28 @@ __device__ __forceinline__ void gb_ltsolve2_body(const double *__restrict__ ab, 
 // ------------------------------------------------------------------------------------------- launch wrappers
 // the factorisation's update of the columns to the right of a panel that swapped no rows
 // (which it did the panel kernel has just decided: the branch is taken on the device, uniformly)
-__global__ __launch_bounds__(GB_T2) void k_gb_trail2(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0, int ncol,
-                                                     const int32_t *__restrict__ ipiv, int64_t jt0, int64_t ntgt) {
+__global__ __launch_bounds__(GB_T2) void k_gb_trail2(double *__restrict__ ab, int ldab, int kl, int ku, int64_t n, int64_t j0_rel,
+                                                     const int32_t *__restrict__ ipiv, GbBlocks B) {
     __shared__ int swapped;
+    const int blk = blockIdx.y;
+    if (j0_rel >= B.len(blk)) return; // (uniform)
+    const int64_t j0 = B.base(blk) + j0_rel;
+    const int ncol = static_cast<int>((B.len(blk) - j0_rel < GB_NB) ? B.len(blk) - j0_rel : GB_NB);
+    // columns to the right that the panel's rows reach: up to j0 + ncol - 1 + ku + kl
+    const int64_t jt0 = j0 + ncol;
+    const int64_t jt1 = (n < j0 + ncol + ku + kl) ? n : j0 + ncol + ku + kl;
+    const int64_t ntgt = jt1 - jt0;
+    if (static_cast<int64_t>(blockIdx.x) * GB_CB >= ntgt) return; // (uniform)
     if (threadIdx.x == 0) swapped = 0;
     __syncthreads();
     if (threadIdx.x < ncol && ipiv[j0 + threadIdx.x] != j0 + threadIdx.x) swapped = 1; // (every writer stores 1)
     __syncthreads();
     if (swapped) gb_apply_body<true>(ab, ldab, kl, ku, n, j0, ncol, ipiv, jt0, ntgt, nullptr, 0);
     else gb_lsolve2_body<true>(ab, ldab, kl, ku, n, j0, ncol, jt0, ntgt, nullptr, 0);
+}
+__global__ __launch_bounds__(256) void k_gb_iota(int64_t n, int32_t *__restrict__ ipiv) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j < n) ipiv[j] = static_cast<int32_t>(j);
 }
 
 // A whole solve in ONE launch: the right-hand sides of different workgroups never meet, so every workgroup walks
@@ -990,6 +1015,8 @@ __global__ __launch_bounds__(GB_T2) void k_gbp_sweep(double *__restrict__ ab, in
 // along the lanes (R is stored column by column: coalesced), the columns cut into GBP_SL slices that are summed through
 // LDS.  delta of the first block in order is zero.
 constexpr int GBP_T = 1024, GBP_SL = 4;
+constexpr int GB_PART_CHUNK = 128;  // right-hand sides per partitioned sweep
+constexpr int GB_PART_MAX = 1024;   // beyond: one sequential walk of all panels for all right-hand sides at once is cheaper
 __global__ __launch_bounds__(GBP_T) void k_gbp_chain(GbPart D, int ncols, const double *__restrict__ bufs, const double *__restrict__ R,
                                                       const double *__restrict__ X, int64_t ldx, double *__restrict__ delta) {
     extern __shared__ double sd[]; // cur[w] | part[GBP_SL][w]
@@ -1067,6 +1094,11 @@ __global__ __launch_bounds__(256) void k_gbp_fix(GbPart D, int ncols, const doub
 }
 
 } // namespace
+
+// (internal, sx_internal.h) the widths sx_bandlu_create_dev accepts: the panel kernel's rows and the solve kernels' LDS block
+bool sx_bandlu_supports(int kl, int ku) {
+    return kl >= 0 && ku >= 0 && static_cast<int64_t>(kl) + GB_NB <= 1536 && gb_lds_bytes(kl + ku + GB_NB) <= 150 * 1024;
+}
 
 SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t nnz, const int32_t *row, const int32_t *col,
                                 const double *val, sx_bandlu **out) {
@@ -1146,36 +1178,48 @@ int gb_part_prepare(sx_bandlu *h);
 SX_API int sx_bandlu_factor_dev(sx_bandlu *h, double pivot_tol, int64_t *n_replaced_out, int32_t *replaced_host,
                                 int32_t *ipiv_host) {
     SX_REQUIRE(h != nullptr, "handle is NULL");
+    return sx_bandlu_factor_blocks_dev(h, pivot_tol, 1, h->n, h->n, h->n, n_replaced_out, replaced_host, ipiv_host);
+}
+
+// The same factorisation for a matrix that is BLOCK DIAGONAL with identity padding between the blocks: block b = columns
+// (and rows) [b stride, b stride + real_len) -- real_len_last for the last one --, then identity up to the next block; no
+// entry couples two blocks.  The blocks' panels are factored side by side, one launch per panel STEP instead of one per
+// panel (a panel is a chain of 32 dependent column steps on one workgroup: 53 us at kl + ku = 230; 3,100 of them in a row
+// at 1e5 rows).  The padding (>= kl + ku + 32 positions, required) keeps what a block's last panels touch -- rows up to
+// kl + 32 below, columns up to ku + kl + 32 to the right -- away from the next block's entries.
+SX_API int sx_bandlu_factor_blocks_dev(sx_bandlu *h, double pivot_tol, int nblocks, int64_t stride, int64_t real_len,
+                                       int64_t real_len_last, int64_t *n_replaced_out, int32_t *replaced_host, int32_t *ipiv_host) {
+    SX_REQUIRE(h != nullptr, "handle is NULL");
     sx_ctx *ctx = h->ctx;
     SX_ENTER(ctx);
     SX_REQUIRE(!h->factored, "already factored");
     hipStream_t s = ctx->stream;
     const int kl = h->kl, ku = h->ku;
     const int64_t n = h->n;
+    SX_REQUIRE(nblocks >= 1 && real_len > 0 && real_len_last > 0, "bad block description");
+    if (nblocks == 1) {
+        SX_REQUIRE(real_len_last == n, "one block covers the matrix");
+    } else {
+        SX_REQUIRE(stride >= real_len + kl + ku + GB_NB, "blocks need kl + ku + 32 positions of identity padding between them");
+        SX_REQUIRE(static_cast<int64_t>(nblocks - 1) * stride + real_len_last == n, "the blocks do not add up to the matrix");
+    }
+    const GbBlocks B{nblocks, stride, nblocks == 1 ? n : real_len, real_len_last};
+    hipLaunchKernelGGL(k_gb_iota, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, n, h->ipiv); // (padding: no swaps)
     const int rows = kl + GB_NB; // rows of a panel: a row per lane and register slot
-    for (int64_t j0 = 0; j0 < n; j0 += GB_NB) {
-        const int ncol = static_cast<int>(std::min<int64_t>(GB_NB, n - j0));
+    const int64_t longest = std::max<int64_t>(B.rl, B.rl_last);
+    const unsigned tg = static_cast<unsigned>(std::max(1, (ku + kl + GB_CB - 1) / GB_CB));
+    const unsigned pb = static_cast<unsigned>(nblocks);
+    for (int64_t j0 = 0; j0 < longest; j0 += GB_NB) {
         if (rows <= 256) // (one wave with three rows per lane measured slower: 88 us per panel against 74 us)
-            hipLaunchKernelGGL((k_gb_panel<256, 1>), dim3(1), dim3(256), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol, h->ipiv,
-                               h->replaced);
+            hipLaunchKernelGGL((k_gb_panel<256, 1>), dim3(pb), dim3(256), 0, s, h->ab, h->ldab, kl, ku, n, j0, pivot_tol, h->ipiv, h->replaced, B);
         else if (rows <= 512)
-            hipLaunchKernelGGL((k_gb_panel<512, 1>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
-                               h->ipiv, h->replaced);
+            hipLaunchKernelGGL((k_gb_panel<512, 1>), dim3(pb), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, pivot_tol, h->ipiv, h->replaced, B);
         else if (rows <= 1024)
-            hipLaunchKernelGGL((k_gb_panel<512, 2>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
-                               h->ipiv, h->replaced);
+            hipLaunchKernelGGL((k_gb_panel<512, 2>), dim3(pb), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, pivot_tol, h->ipiv, h->replaced, B);
         else
-            hipLaunchKernelGGL((k_gb_panel<512, 3>), dim3(1), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, ncol, pivot_tol,
-                               h->ipiv, h->replaced);
-        // columns to the right that the panel's rows reach: up to j0 + ncol - 1 + ku + kl
-        const int64_t jt0 = j0 + ncol;
-        const int64_t jt1 = std::min<int64_t>(n, j0 + ncol + ku + kl);
-        const int64_t ntgt = jt1 - jt0;
-        if (ntgt > 0) {
-            const int R = static_cast<int>(std::min<int64_t>(n - j0, static_cast<int64_t>(kl) + ncol));
-            hipLaunchKernelGGL(k_gb_trail2, dim3(static_cast<unsigned>((ntgt + GB_CB - 1) / GB_CB)), dim3(GB_T2), gb_lds_bytes(R), s, h->ab,
-                               h->ldab, kl, ku, n, j0, ncol, h->ipiv, jt0, ntgt);
-        }
+            hipLaunchKernelGGL((k_gb_panel<512, 3>), dim3(pb), dim3(512), 0, s, h->ab, h->ldab, kl, ku, n, j0, pivot_tol, h->ipiv, h->replaced, B);
+        if (ku + kl > 0)
+            hipLaunchKernelGGL(k_gb_trail2, dim3(tg, pb), dim3(GB_T2), gb_lds_bytes(kl + GB_NB), s, h->ab, h->ldab, kl, ku, n, j0, h->ipiv, B);
     }
     SX_HIP(hipGetLastError());
     h->factored = true;
@@ -1250,8 +1294,31 @@ int gb_part_prepare(sx_bandlu *h) {
     if (hipMalloc(&h->part_buf, sizeof(double) * DU.rows_total() * GB_CB) != hipSuccess) return SX_OK;
     if (hipMalloc(&h->part_delta, sizeof(double) * static_cast<size_t>(DU.P) * GB_CB * DU.w) != hipSuccess) return SX_OK;
     SX_HIP(hipGetLastError());
+    h->part_cols = GB_CB;
     h->part_state = 1;
     return SX_OK;
+}
+// work buffers of the partitioned sweeps for `ncols` right-hand sides at once (the blocks of one sweep run side by side per
+// group of 8 columns, the chain per column: 64 columns cost about what 8 do); keeps what it has when the memory is short
+void gb_part_reserve(sx_bandlu *h, int ncols) {
+    if (ncols <= h->part_cols) return;
+    const GbPart DU = gb_part_desc(h, 1);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const size_t need = sizeof(double) * (DU.rows_total() + static_cast<size_t>(DU.P) * DU.w) * static_cast<size_t>(ncols);
+    if (static_cast<double>(need) > 0.25 * static_cast<double>(free_b)) return;
+    (void)hipStreamSynchronize(h->ctx->stream);
+    double *buf = nullptr, *delta = nullptr;
+    if (hipMalloc(&buf, sizeof(double) * DU.rows_total() * static_cast<size_t>(ncols)) != hipSuccess) return;
+    if (hipMalloc(&delta, sizeof(double) * static_cast<size_t>(DU.P) * static_cast<size_t>(ncols) * DU.w) != hipSuccess) {
+        (void)hipFree(buf);
+        return;
+    }
+    (void)hipFree(h->part_buf);
+    (void)hipFree(h->part_delta);
+    h->part_buf = buf;
+    h->part_delta = delta;
+    h->part_cols = ncols;
 }
 void gb_part_sweep(sx_bandlu *h, int kind, int ncols, double *X, int64_t ldx) {
     const GbPart D = gb_part_desc(h, kind);
@@ -1280,11 +1347,16 @@ SX_API int sx_bandlu_solve_dev(sx_bandlu *h, int trans, int64_t nrhs, double *X,
     const int64_t npanel = (n + GB_NB - 1) / GB_NB;
     static const bool slow = getenv("SX_BANDLU_STEPWISE") != nullptr; // the step-by-step panel bodies everywhere (A/B runs, tests)
     (void)npanel;
-    if (nrhs <= GB_CB && !slow) { // a few dense right-hand sides: the sweeps cut into blocks that run side by side
+    if (nrhs <= GB_PART_MAX && !slow) { // dense right-hand sides, not thousands: the sweeps cut into blocks that run side by side
         if (h->part_state == 0) SX_TRY(gb_part_prepare(h));
         if (h->part_state == 1) {
-            gb_part_sweep(h, trans ? 2 : 0, static_cast<int>(nrhs), X, ldx);
-            gb_part_sweep(h, trans ? 3 : 1, static_cast<int>(nrhs), X, ldx);
+            gb_part_reserve(h, static_cast<int>(std::min<int64_t>(nrhs, GB_PART_CHUNK)));
+            for (int64_t c0 = 0; c0 < nrhs; c0 += h->part_cols) {
+                const int kc = static_cast<int>(std::min<int64_t>(h->part_cols, nrhs - c0));
+                double *Xc = X + static_cast<size_t>(c0) * ldx;
+                gb_part_sweep(h, trans ? 2 : 0, kc, Xc, ldx);
+                gb_part_sweep(h, trans ? 3 : 1, kc, Xc, ldx);
+            }
             SX_HIP(hipGetLastError());
             return SX_OK;
         }

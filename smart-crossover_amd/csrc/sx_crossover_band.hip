@@ -1,24 +1,30 @@
-// Sparse crossover (kernel group K16s): from the point the first-order stage (sx_pdlp.hip) leaves to an optimal
-// vertex and its basis WITHOUT a dense m x m inverse.  Stands where the reference's backends run their crossover
-// behind the barrier (lp_methods/algorithms.py:50-54 -> solver_caller/gurobi.py:111-115, all inside Gurobi).
+// Sparse crossover (kernel group K16s): from the point the first-order stage (sx_pdlp.hip) leaves -- or from a given
+// basis -- to an optimal vertex and its basis WITHOUT a dense m x m inverse.  Stands where the reference's backends run
+// their crossover behind the barrier (lp_methods/algorithms.py:50-54 -> solver_caller/gurobi.py:111-115) and their
+// warm-started simplex (lp_methods/algorithms.py:69-74), all inside Gurobi.
 //
-// Rounds 1-2 kept B^-1 explicitly (8 m^2 bytes; 1e5 rows = 80 GB, installed by m pivots in 47 s).  Here:
-//   * the starting basis B0 is CHOSEN for its structure: rows in their natural order, the interior columns
-//     (and the slacks of inactive rows) matched to the rows by position, dense rows set aside and covered by
-//     their own logical -> B0 = [B11 0; B21 I] with B11 a band matrix.  Interior columns that find no place
-//     stay superbasic; a row that finds no column is covered by its logical (an artificial for an '=' row,
-//     driven out by phase 1 like any infeasible basic variable);
-//   * B11 is factored ONCE by the band LU of sx_bandlu.hip (pivot-less columns repaired in place);
-//   * the simplex then works on an explicit TABLEAU of the few columns that can still move -- the superbasic
-//     ones plus what pricing adds: T = B^-1 A_J (m x |J|, column major in HBM).  A pivot is a ratio test down
-//     one column, a copy of one row, and a rank-one update of T (rows and columns the pivot does not touch
-//     are skipped); every entering column is also kept as an eta vector, so duals (B^-T c_B = B0^-T E_1^T ..
-//     E_k^T c_B) and new tableau columns (E_k .. E_1 B0^-1 a_j) never need a second factorisation;
+// Rounds 1-2 kept B^-1 explicitly (8 m^2 bytes); round 3 factored a band basis once, covered the dense (linking) rows by
+// their logicals and paid for it with one pivot per linking row on a 66-99 GB tableau.  Now:
+//   * the basis is factored in BORDERED form (sx_border.h): rows in their natural (or Cuthill-McKee) order, dense rows set
+//     aside; every basic variable is matched to a band row by entry size -> B11, a band matrix (K16f); what finds no band
+//     row -- the linking activities, logicals of dense rows -- forms the border together with the dense rows, and the
+//     Schur complement of the border is factored by the dense LU (K16g).  EVERY basic variable is in the factors, so a
+//     fresh factorisation of the current basis (full eta file, numerical trouble, final check) is a true
+//     refactorisation, and a given basis (vbasis_in / cbasis_in) is taken as it is.  Columns the two LUs find
+//     dependent leave the basis (superbasic), the logical of the row in question takes their place;
+//   * the simplex works on an explicit TABLEAU of the few columns that can still move -- the superbasic ones plus what
+//     pricing adds: T = B^-1 A_J (positions x |J|, column major in HBM, grown on demand).  A pivot is a ratio test down
+//     one column, a copy of one row, and a rank-one update of T deferred in product form (64 per fold); every entering
+//     column is also kept as an eta vector, so duals (B^-T c_B = B0^-T E_1^T .. E_k^T c_B) and new tableau columns
+//     (E_k .. E_1 B0^-1 a_j) need no second factorisation until the eta file is full;
 //   * when no tracked column prices out, all other columns are priced with those duals (the K1 walk) and the
-//     violators join the tableau -- column generation, as in the reference's network crossover.
-// Memory O(nnz + m (kl + ku) + m |J|).  Everything that decides a pivot runs on the device; the host replays
+//     violators join the tableau -- column generation, as in the reference's network crossover;
+//   * before a vertex is called optimal its row residuals (one K2 walk) and the reduced costs of its basic columns are
+//     checked against A itself; beyond the tolerances the basis is factored afresh and the run goes on.
+// Memory O(nnz + m (kl + ku) + nb^2 + m |J|).  Everything that decides a pivot runs on the device; the host replays
 // batches of pivots and reads one status word per batch.
 #include "sx_internal.h"
+#include "sx_border.h"
 
 #include <algorithm>
 #include <cstring>
@@ -94,19 +100,6 @@ __global__ __launch_bounds__(TB_WG) void k_tb_scatter_cols(int64_t nslots, const
         return;
     }
     for (int64_t k = cptr[v]; k < cptr[v + 1]; ++k) col[eqidx[cidx[k]]] = cval[k];
-}
-
-// T[m1 + dr, s] -= sum_k B21(dr, pos_k) T[pos_k, s]
-__global__ __launch_bounds__(TB_WG) void k_tb_dense_rows(int64_t ndr, int64_t nrhs, const int64_t *__restrict__ ptr,
-                                                         const int32_t *__restrict__ pos, const double *__restrict__ val,
-                                                         double *__restrict__ T, int64_t m, int64_t m1) {
-    const int64_t t = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x;
-    if (t >= ndr * nrhs) return;
-    const int64_t dr = t % ndr, s = t / ndr;
-    double *col = T + static_cast<size_t>(s) * m;
-    double acc = 0.0;
-    for (int64_t k = ptr[dr]; k < ptr[dr + 1]; ++k) acc += val[k] * col[pos[k]];
-    col[m1 + dr] -= acc;
 }
 
 __device__ __forceinline__ double tb_block_sum(double v, double *sm) {
@@ -879,19 +872,118 @@ int down(hipStream_t s, std::vector<T> &dst, const T *src, size_t count) {
 inline unsigned gridof(int64_t n) { return static_cast<unsigned>(n > 0 ? (n + TB_WG - 1) / TB_WG : 1); }
 inline unsigned gridcap(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(gridof(n), 1 << 20)); } // for grid-stride kernels
 
+
+// per-slot arrays of the tableau (one slot per tracked column) and the tableau itself; grown when pricing brings in more
+// columns than there is room for (the explicit tableau of round 3 was sized once, at 90 % of the free memory)
+struct TbSlots {
+    int64_t mp = 0, cap = 0;
+    double *T = nullptr, *xJ = nullptr, *lJ = nullptr, *uJ = nullptr, *cJ = nullptr, *dJ = nullptr, *d1 = nullptr, *rowbuf = nullptr,
+           *vbuf = nullptr, *ebG = nullptr, *ebS = nullptr;
+    int32_t *varJ = nullptr, *statJ = nullptr, *s0 = nullptr, *sbase = nullptr, *elist = nullptr;
+    TbSlots() = default;
+    TbSlots(const TbSlots &) = delete;
+    TbSlots &operator=(const TbSlots &) = delete;
+    ~TbSlots() {
+        for (void *q : {(void *)T, (void *)xJ, (void *)lJ, (void *)uJ, (void *)cJ, (void *)dJ, (void *)d1, (void *)rowbuf, (void *)vbuf, (void *)ebG,
+                        (void *)ebS, (void *)varJ, (void *)statJ, (void *)s0, (void *)sbase, (void *)elist})
+            (void)hipFree(q);
+    }
+    void swap_with(TbSlots &o) {
+        std::swap(mp, o.mp); std::swap(cap, o.cap); std::swap(T, o.T); std::swap(xJ, o.xJ); std::swap(lJ, o.lJ); std::swap(uJ, o.uJ);
+        std::swap(cJ, o.cJ); std::swap(dJ, o.dJ); std::swap(d1, o.d1); std::swap(rowbuf, o.rowbuf); std::swap(vbuf, o.vbuf); std::swap(ebG, o.ebG);
+        std::swap(ebS, o.ebS); std::swap(varJ, o.varJ); std::swap(statJ, o.statJ); std::swap(s0, o.s0); std::swap(sbase, o.sbase); std::swap(elist, o.elist);
+    }
+    static size_t bytes_for(int64_t mp_, int64_t cap_) {
+        return sizeof(double) * (static_cast<size_t>(mp_) * cap_ + static_cast<size_t>(7 + TB_K + 2 * TB_EB) * cap_) + sizeof(int32_t) * 5 * static_cast<size_t>(cap_);
+    }
+    // capacity newcap, the first `keep` slots (and tableau columns) carried over
+    int reserve(hipStream_t s, int64_t mp_, int64_t newcap, int64_t keep) {
+        if (newcap <= cap && mp_ == mp) return SX_OK;
+        TbSlots nw;
+        nw.mp = mp_;
+        nw.cap = newcap;
+        const size_t c = static_cast<size_t>(newcap);
+#define TB_GET(field, count)                                                                                                       \
+    if (hipMalloc(reinterpret_cast<void **>(&nw.field), sizeof(*nw.field) * (count)) != hipSuccess) {                               \
+        sx_set_error("hipMalloc of %zu bytes failed in the sparse crossover (tableau of %lld columns over %lld positions)",        \
+                     sizeof(*nw.field) * (count), (long long)newcap, (long long)mp_);                                              \
+        return SX_ERR_NOMEM;                                                                                                       \
+    }
+        TB_GET(T, static_cast<size_t>(mp_) * c)
+        TB_GET(xJ, c) TB_GET(lJ, c) TB_GET(uJ, c) TB_GET(cJ, c) TB_GET(dJ, c) TB_GET(d1, c) TB_GET(rowbuf, c)
+        TB_GET(vbuf, static_cast<size_t>(TB_K) * c) TB_GET(ebG, static_cast<size_t>(TB_EB) * c) TB_GET(ebS, static_cast<size_t>(TB_EB) * c)
+        TB_GET(varJ, c) TB_GET(statJ, c) TB_GET(s0, c) TB_GET(sbase, c) TB_GET(elist, c)
+#undef TB_GET
+        if (keep > 0) {
+            SX_REQUIRE(mp_ == mp && keep <= cap, "internal: tableau columns cannot be carried over");
+            const size_t k = static_cast<size_t>(keep);
+            SX_HIP(hipMemcpyAsync(nw.T, T, sizeof(double) * static_cast<size_t>(mp_) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.xJ, xJ, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.lJ, lJ, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.uJ, uJ, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.cJ, cJ, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.dJ, dJ, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.varJ, varJ, sizeof(int32_t) * k, hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(nw.statJ, statJ, sizeof(int32_t) * k, hipMemcpyDeviceToDevice, s));
+        }
+        SX_HIP(hipMemsetAsync(nw.s0, 0, sizeof(int32_t) * c, s));       // no pending update anywhere
+        SX_HIP(hipMemsetAsync(nw.sbase, 0xFF, sizeof(int32_t) * c, s)); // (-1: every slot's base column is T's)
+        SX_HIP(hipStreamSynchronize(s));
+        swap_with(nw); // (nw's destructor frees the old arrays)
+        return SX_OK;
+    }
+};
+
+// rows of a sparse matrix from (row, index, value) triplets (counting sort, stable); `list` != nullptr: only the rows
+// that hold an entry, listed in ascending order
+struct HostRows {
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> idx, list;
+    std::vector<double> val;
+};
+void rows_from_triplets(int64_t nrows, const std::vector<int32_t> &row, const std::vector<int32_t> &idx, const std::vector<double> &val, bool compact,
+                        HostRows &out) {
+    std::vector<int64_t> cnt(static_cast<size_t>(nrows) + 1, 0);
+    for (int32_t r : row) ++cnt[static_cast<size_t>(r) + 1];
+    for (int64_t r = 0; r < nrows; ++r) cnt[r + 1] += cnt[r];
+    out.idx.assign(row.size(), 0);
+    out.val.assign(row.size(), 0.0);
+    std::vector<int64_t> at(cnt.begin(), cnt.end() - 1);
+    for (size_t e = 0; e < row.size(); ++e) {
+        const int64_t o = at[row[e]]++;
+        out.idx[o] = idx[e];
+        out.val[o] = val[e];
+    }
+    out.ptr.clear();
+    out.list.clear();
+    if (!compact) {
+        out.ptr = cnt;
+        return;
+    }
+    out.ptr.push_back(0);
+    for (int64_t r = 0; r < nrows; ++r)
+        if (cnt[r + 1] > cnt[r]) {
+            out.list.push_back(static_cast<int32_t>(r));
+            out.ptr.push_back(cnt[r + 1]);
+        }
+}
+
 } // namespace
 
-SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
-                                 const double *u, const uint8_t *row_is_lt, const double *x_start, int64_t max_iter,
-                                 double feas_tol, double opt_tol, double *x_out, double *y_out, int8_t *vbasis_out,
-                                 int8_t *cbasis_out, sx_simplex_result *result) {
+// One entry for the three ways the sparse crossover is started: from the first-order point alone (vbasis_in == NULL: the
+// basis is guessed from the margins), or from a given basis (the reference's warm-started final solve,
+// lp_methods/algorithms.py:69-74; sx_crossover_band_dev passes NULL).
+SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                       const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
+                                       const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
+                                       double *y_out, int8_t *vbasis_out, int8_t *cbasis_out, sx_simplex_result *result) {
     SX_ENTER(ctx);
     SX_REQUIRE(A && b && c && l && u && x_start && result, "NULL argument");
+    SX_REQUIRE((vbasis_in == nullptr) == (cbasis_in == nullptr), "vbasis_in and cbasis_in come together");
     SX_REQUIRE(A->csr_ptr && A->csc_ptr, "the sparse crossover needs both layouts of A");
     const int64_t m = A->m, n = A->n;
     SX_REQUIRE(m > 0 && n > 0 && m + n < 2000000000LL, "problem size");
     const bool trace = getenv("SX_SPX_TRACE") != nullptr;
-    const bool dense_solves = getenv("SX_BAND_DENSE_SOLVES") != nullptr; // A/B: tableau columns through the plain band solve
     hipStream_t s = ctx->stream;
     auto now = []() {
         timespec ts;
@@ -911,6 +1003,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     std::vector<int32_t> cidx;
     std::vector<double> cval, hb, hc, hl, hu, hx, hslack;
     std::vector<uint8_t> hlt(static_cast<size_t>(m), 0);
+    std::vector<int8_t> vb_in, cb_in;
     SX_TRY(down(s, cptr, A->csc_ptr, static_cast<size_t>(n) + 1));
     SX_TRY(down(s, rptr, A->csr_ptr, static_cast<size_t>(m) + 1));
     SX_TRY(down(s, cidx, A->csc_idx, static_cast<size_t>(A->nnz)));
@@ -921,6 +1014,10 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     SX_TRY(down(s, hu, u, static_cast<size_t>(n)));
     SX_TRY(down(s, hx, x_start, static_cast<size_t>(n)));
     if (row_is_lt) SX_HIP(hipMemcpyAsync(hlt.data(), row_is_lt, static_cast<size_t>(m), hipMemcpyDeviceToHost, s));
+    if (vbasis_in) {
+        SX_TRY(down(s, vb_in, vbasis_in, static_cast<size_t>(n)));
+        SX_TRY(down(s, cb_in, cbasis_in, static_cast<size_t>(m)));
+    }
     double *d_tmpm = nullptr, *d_tmpn = nullptr, *d_rc = nullptr;
     SX_TRY(dev.get(static_cast<size_t>(m), &d_tmpm));
     SX_TRY(dev.get(static_cast<size_t>(n), &d_tmpn));
@@ -939,6 +1036,12 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         else rows_band.push_back(static_cast<int32_t>(i));
     }
     const int64_t m1 = static_cast<int64_t>(rows_band.size()), ndr = static_cast<int64_t>(rows_dense.size());
+    constexpr int64_t MAX_NB = 16384; // rows of the Schur complement the dense LU takes
+    if (ndr > MAX_NB) {
+        sx_set_error("%lld rows with more than %lld entries: the border of the basis would pass the dense LU's %lld rows", (long long)ndr,
+                     (long long)dense_thr, (long long)MAX_NB);
+        return SX_ERR_UNSUPPORTED;
+    }
     std::vector<int32_t> rowb(static_cast<size_t>(m), -1);
     // ---- the order of the band rows.  Natural order first (staged models are written stage after stage); when
     // that leaves some column taller than a band can be, a Cuthill-McKee order of the rows (breadth first over
@@ -1021,15 +1124,38 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     int32_t *d_eqidx = nullptr;
     SX_TRY(dev.get(eqidx.size(), &d_eqidx));
     SX_TRY(up(s, d_eqidx, eqidx));
-    // ------------------------------------------------------------------ the first basis guess: who is interior
+    // ------------------------------------------------------------------ the first basic set
     const double MARGIN = 1e-7;
-    std::vector<uint8_t> pick(static_cast<size_t>(NV), 0); // may sit in the basis of the next epoch
-    std::vector<int32_t> tracked;                           // columns of the tableau that are not basic
-    {
+    std::vector<uint8_t> is_basic(static_cast<size_t>(NV), 0); // the variables the next factorisation has to hold
+    std::vector<int32_t> tracked;                               // columns of the tableau that are not basic
+    std::vector<int8_t> atup(static_cast<size_t>(NV), 0);
+    std::vector<double> margin; // of the first guess (empty for a given basis): the border takes its columns in this order
+    // smallest pivot the two LUs accept.  A GUESSED basis (the m largest margins of a first-order point) may hold columns
+    // that are all but dependent -- its basic solution then lies far from the point and phase 1 pays for it pivot by pivot
+    // -- so its LUs set such columns aside (they stay superbasic, a logical takes their place); a basis the simplex has
+    // reached, or one that was given, is kept unless it is singular to working accuracy
+    const double tol_band_guess = getenv("SX_BAND_PIVTOL_B") ? atof(getenv("SX_BAND_PIVTOL_B")) : 1e-3;
+    const double tol_schur_guess = getenv("SX_BAND_PIVTOL_S") ? atof(getenv("SX_BAND_PIVTOL_S")) : 1e-1;
+    const double tol_band_keep = 1e-7, tol_schur_keep = 1e-9;
+    if (vbasis_in) { // a given basis: codes as in output.py (0 basic, -1 at lower, -2 at upper, -3 superbasic at x_start)
+        for (int64_t j = 0; j < n; ++j) {
+            const int code = vb_in[j];
+            if (code == 0) is_basic[j] = 1;
+            else if (code == -3) tracked.push_back(static_cast<int32_t>(j));
+            else {
+                double v = code == -2 ? hu[j] : hl[j];
+                if (std::isinf(v)) v = code == -2 ? hl[j] : hu[j];
+                if (std::isinf(v)) v = 0.0;
+                hx[j] = v;
+            }
+        }
+        for (int64_t i = 0; i < m; ++i)
+            if (cb_in[i] == 0) is_basic[n + i] = 1;
+    } else {
         SX_TRY(sx_score_rows_dev(ctx, A, x_start, b, nullptr, 0.0, d_tmpm, nullptr)); // slack = b - A x
         SX_TRY(down(s, hslack, d_tmpm, static_cast<size_t>(m)));
         SX_HIP(hipStreamSynchronize(s));
-        std::vector<double> margin(static_cast<size_t>(NV), -1.0);
+        margin.assign(static_cast<size_t>(NV), -1.0);
         std::vector<int64_t> cand;
         for (int64_t j = 0; j < n; ++j) {
             const double mg = std::min(hx[j] - hl[j], hu[j] - hx[j]);
@@ -1047,68 +1173,57 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             std::nth_element(cand.begin(), cand.begin() + m, cand.end(),
                              [&](int64_t a, int64_t bb) { return margin[a] > margin[bb] || (margin[a] == margin[bb] && a < bb); });
         for (size_t k = 0; k < cand.size(); ++k) {
-            if (static_cast<int64_t>(k) < m) pick[cand[k]] = 1;
+            if (static_cast<int64_t>(k) < m) is_basic[cand[k]] = 1;
             else tracked.push_back(static_cast<int32_t>(cand[k]));
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] m=%lld n=%lld: %zu interior candidates, band rows %lld, dense rows %lld\n", (long long)m, (long long)n, cand.size(), (long long)m1, (long long)ndr);
     }
-    // ------------------------------------------------------------------ capacities, the big blocks (once)
-    // basis changes before the basis is factored afresh (bounds the eta file and the drift of the tableau).  A fresh
-    // start covers the dense rows by their logicals again, so it is not free: as many as a quarter of the memory holds
-    int64_t EPOCH = 4096;
-    int64_t capJ = 0; // fixed once the first matching has told how many columns start outside the basis
-    {
-        size_t free_b = 0, total_b = 0;
-        SX_HIP(hipMemGetInfo(&free_b, &total_b));
-        EPOCH = std::min<int64_t>(20000, std::max<int64_t>(1024, static_cast<int64_t>(0.25 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m)))));
-        if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
-    }
-    double *d_T = nullptr, *d_eta = nullptr, *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr;
-    double *d_xJ = nullptr, *d_lJ = nullptr, *d_uJ = nullptr, *d_cJ = nullptr, *d_dJ = nullptr, *d_d1 = nullptr, *d_rowbuf = nullptr,
-           *d_part = nullptr, *d_infpart = nullptr, *d_vec = nullptr;
-    int32_t *d_head = nullptr, *d_varJ = nullptr, *d_statJ = nullptr, *d_eta_r = nullptr, *d_blist = nullptr;
-    int32_t *d_pr = nullptr, *d_s0 = nullptr, *d_sbase = nullptr, *d_elist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr;
-    double *d_ebG = nullptr, *d_ebM = nullptr, *d_ebS = nullptr;
-    double *d_vbuf = nullptr, *d_gu = nullptr;
-    TbPart *d_rpart = nullptr;
+    // ------------------------------------------------------------------ small per-call blocks
     TbState *d_st = nullptr;
-    const int nblk = static_cast<int>(gridof(m));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_xB));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_lB));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_uB));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_cB));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_g));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_vec));
-    SX_TRY(dev.get(static_cast<size_t>(m), &d_head));
-    SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_part));
-    SX_TRY(dev.get(static_cast<size_t>(nblk), &d_blist));
-    SX_TRY(dev.get(static_cast<size_t>(2 * nblk), &d_infpart));
-    SX_TRY(dev.get(static_cast<size_t>(nblk), &d_infoff));
-    SX_TRY(dev.get(static_cast<size_t>(TB_INFLIST), &d_inflist));
-    SX_TRY(dev.get(static_cast<size_t>(nblk), &d_rpart));
     SX_TRY(dev.get(1, &d_st));
+    int32_t *d_pr = nullptr;
+    double *d_gu = nullptr, *d_ebM = nullptr;
+    SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_pr));
+    SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_gu));
+    SX_TRY(dev.get(static_cast<size_t>(TB_EB) * TB_EB, &d_ebM));
 
     long long tot_iters = 0, tot_pivots = 0, tot_flips = 0, tot_degen = 0;
     int64_t added_total = 0;
-    int epochs = 0, final_status = 4, bad_epochs = 0;
+    int epochs = 0, final_status = 4, bad_epochs = 0, check_epochs = 0;
     std::vector<double> hy(static_cast<size_t>(m), 0.0);
     std::vector<int8_t> vstat(static_cast<size_t>(NV), 0); // 0 non-basic at a bound, 1 basic, 2 tracked
-    std::vector<int8_t> atup(static_cast<size_t>(NV), 0);
     std::vector<double> xlog(static_cast<size_t>(m), 0.0);  // values of tracked logicals
-    double viol_max = 0.0;
+    std::vector<int64_t> prev_pos;                          // band position -> the variable that sat there and never moved
+    double viol_max = 0.0, resid_max = 0.0;
+    size_t peak_bytes = 0;
 
     for (;;) {
         ++epochs;
+        const bool guessed = epochs == 1 && !vbasis_in; // the basic set is a guess from the margins of the point
         DevBufs edev; // this epoch's device arrays
-        // ---------------------------------------------------------------- columns to rows: who covers which band row
-        // Every band row gets ONE variable and that variable's position is the row's: a row whose own logical is
-        // picked keeps it; the picked columns are then matched to the free rows greedily by entry size, largest
-        // first (large entries on the diagonal, and a band no wider than a column is tall: a column only ever
-        // sits on a row it has an entry in); rows no column takes are covered by their logical, columns that find
-        // no row become tracked (superbasic).
-        std::vector<int64_t> head(static_cast<size_t>(m), -1);
-        for (int64_t p = 0; p < m1; ++p)
-            if (pick[n + rows_band[p]]) head[p] = n + rows_band[p];
+        // ---------------------------------------------------------------- columns to rows: who sits on which band row
+        // Every band row gets at most ONE variable, whose position is the row's: a variable that sat there in the last
+        // factorisation and is still basic stays; a row whose own logical is basic keeps it; the other basic columns are
+        // matched to the free rows greedily by entry size, largest first (large entries on the diagonal, and a band no
+        // wider than a column is tall: a column only ever sits on a row it has an entry in).  A row no column takes holds
+        // a PLACEHOLDER (unit vector; border row "its value = 0"), a column that finds no row goes to the BORDER.
+        std::vector<int64_t> bvar(static_cast<size_t>(m1), -1);
+        std::vector<uint8_t> placed(static_cast<size_t>(NV), 0);
+        if (!prev_pos.empty())
+            for (int64_t p = 0; p < m1; ++p) {
+                const int64_t v = prev_pos[p];
+                if (v >= 0 && is_basic[v] && !placed[v]) {
+                    bvar[p] = v;
+                    placed[v] = 1;
+                }
+            }
+        for (int64_t p = 0; p < m1; ++p) {
+            const int64_t v = n + rows_band[p];
+            if (bvar[p] < 0 && is_basic[v] && !placed[v]) {
+                bvar[p] = v;
+                placed[v] = 1;
+            }
+        }
         {
             struct Ent {
                 double a;
@@ -1117,12 +1232,12 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             };
             std::vector<Ent> ents;
             for (int64_t j = 0; j < n; ++j) {
-                if (!pick[j]) continue;
+                if (!is_basic[j] || placed[j]) continue;
                 const size_t first = ents.size();
                 for (int64_t k = cptr[j]; k < cptr[j + 1]; ++k) {
                     const int32_t ib = rowb[cidx[k]];
                     const double a = std::fabs(cval[k]);
-                    if (ib >= 0 && head[ib] < 0 && a > 1e-6) ents.push_back(Ent{a, ib, j});
+                    if (ib >= 0 && bvar[ib] < 0 && a > 1e-6) ents.push_back(Ent{a, ib, j});
                 }
                 // a column's candidates by band row (a handful: insertion sort), so that the stable sort below leaves
                 // equal sizes in (variable, band row) order
@@ -1139,164 +1254,378 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 std::vector<Ent> tmp(ents.size());
                 std::vector<uint32_t> hist(65536);
                 auto key = [](const Ent &e) {
-                    uint64_t b;
-                    std::memcpy(&b, &e.a, sizeof(b));
-                    return ~b;
+                    uint64_t bits;
+                    std::memcpy(&bits, &e.a, sizeof(bits));
+                    return ~bits;
                 };
-                for (int pass = 0; pass < 4; ++pass) {
+                for (int pass = 0; pass < 4 && ents.size() > 1; ++pass) {
                     const int sh = 16 * pass;
                     std::fill(hist.begin(), hist.end(), 0u);
                     for (const Ent &e : ents) ++hist[(key(e) >> sh) & 0xFFFF];
                     uint32_t run = 0;
-                    for (uint32_t &h : hist) {
-                        const uint32_t c = h;
-                        h = run;
-                        run += c;
+                    for (uint32_t &hh_ : hist) {
+                        const uint32_t cc = hh_;
+                        hh_ = run;
+                        run += cc;
                     }
                     for (const Ent &e : ents) tmp[hist[(key(e) >> sh) & 0xFFFF]++] = e;
                     ents.swap(tmp);
                 }
             }
-            std::vector<uint8_t> placed(static_cast<size_t>(n), 0);
             for (const Ent &e : ents)
-                if (!placed[e.var] && head[e.ib] < 0) {
-                    head[e.ib] = e.var;
+                if (!placed[e.var] && bvar[e.ib] < 0) {
+                    bvar[e.ib] = e.var;
                     placed[e.var] = 1;
                 }
         }
-        int64_t n_art = 0;
-        for (int64_t p = 0; p < m1; ++p)
-            if (head[p] < 0) {
-                head[p] = n + rows_band[p];
-                ++n_art;
-            }
-        for (int64_t k = 0; k < ndr; ++k) head[m1 + k] = n + rows_dense[k];
-        // band triplets, the dense rows' entries, band widths
+        // band triplets (a placeholder or a logical: the unit vector of the row), band widths
         std::vector<int32_t> trow, tcol;
         std::vector<double> tval;
-        std::vector<std::vector<std::pair<int32_t, double>>> b21(static_cast<size_t>(ndr));
         int kl = 0, ku = 0;
         for (int64_t p = 0; p < m1; ++p) {
-            const int64_t v = head[p];
-            if (v >= n) {
+            const int64_t v = bvar[p];
+            if (v < 0 || v >= n) {
                 trow.push_back(static_cast<int32_t>(p));
                 tcol.push_back(static_cast<int32_t>(p));
                 tval.push_back(1.0);
                 continue;
             }
             for (int64_t k = cptr[v]; k < cptr[v + 1]; ++k) {
-                const int32_t i = cidx[k], ib = rowb[i];
+                const int32_t ib = rowb[cidx[k]];
                 if (ib >= 0) {
                     trow.push_back(ib);
                     tcol.push_back(static_cast<int32_t>(p));
                     tval.push_back(cval[k]);
                     kl = std::max<int>(kl, ib - static_cast<int>(p));
                     ku = std::max<int>(ku, static_cast<int>(p) - ib);
-                } else {
-                    b21[static_cast<size_t>(eqidx[i] - m1)].emplace_back(static_cast<int32_t>(p), cval[k]);
                 }
             }
         }
-        if (kl + 32 > 1536 || kl + ku + 32 > 2400) {
-            sx_set_error("the basis is not a band matrix in the natural order of the rows (kl = %d, ku = %d after setting %lld dense rows aside)",
-                         kl, ku, (long long)ndr);
+        if (!sx_bandlu_supports(kl, ku)) {
+            sx_set_error("the basis is not a band matrix in the order of the rows (kl = %d, ku = %d after setting %lld dense rows aside)", kl, ku,
+                         (long long)ndr);
             return SX_ERR_UNSUPPORTED;
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: matching and band assembly done at %.1f ms\n", epochs, now() - t_begin);
         // ---------------------------------------------------------------- factor B11
-        int32_t *d_trow = nullptr, *d_tcol = nullptr;
-        double *d_tval = nullptr;
-        SX_TRY(edev.get(trow.size(), &d_trow));
-        SX_TRY(edev.get(tcol.size(), &d_tcol));
-        SX_TRY(edev.get(tval.size(), &d_tval));
-        SX_TRY(up(s, d_trow, trow));
-        SX_TRY(up(s, d_tcol, tcol));
-        SX_TRY(up(s, d_tval, tval));
         sx_bandlu *lu = nullptr;
-        struct LuGuard {
+        sx_denselu *dl = nullptr;
+        struct FactorGuard {
             sx_bandlu *&h;
-            ~LuGuard() {
+            sx_denselu *&d;
+            ~FactorGuard() {
                 if (h) sx_bandlu_destroy(h);
+                if (d) sx_denselu_destroy(d);
             }
-        } lug{lu};
+        } fguard{lu, dl};
+        std::vector<int32_t> ph_row(static_cast<size_t>(m1), -1); // the row whose unit vector a placeholder is
         int64_t nrep = 0;
         if (m1 > 0) {
+            int32_t *d_trow = nullptr, *d_tcol = nullptr;
+            double *d_tval = nullptr;
+            DevBufs tdev;
+            SX_TRY(tdev.get(trow.size(), &d_trow));
+            SX_TRY(tdev.get(tcol.size(), &d_tcol));
+            SX_TRY(tdev.get(tval.size(), &d_tval));
+            SX_TRY(up(s, d_trow, trow));
+            SX_TRY(up(s, d_tcol, tcol));
+            SX_TRY(up(s, d_tval, tval));
             SX_TRY(sx_bandlu_create_dev(ctx, m1, kl, ku, static_cast<int64_t>(tval.size()), d_trow, d_tcol, d_tval, &lu));
             std::vector<int32_t> rep(static_cast<size_t>(m1)), piv(static_cast<size_t>(m1));
-            SX_TRY(sx_bandlu_factor_dev(lu, 1e-7, &nrep, rep.data(), piv.data()));
-            // replaced columns: the logical of the row that sat on the diagonal takes the position
+            SX_TRY(sx_bandlu_factor_dev(lu, guessed ? tol_band_guess : tol_band_keep, &nrep, rep.data(), piv.data()));
+            // a replaced column stands for the unit vector of the row that sat on its diagonal: a placeholder; the column
+            // itself goes to the border
             std::vector<int32_t> rowof(static_cast<size_t>(m1));
             std::iota(rowof.begin(), rowof.end(), 0);
             for (int64_t j = 0; j < m1; ++j) {
-                if (rep[j]) head[j] = n + rows_band[rowof[j]];
-                else if (piv[j] != j) std::swap(rowof[j], rowof[piv[j]]);
+                if (rep[j]) {
+                    if (bvar[j] >= 0) placed[bvar[j]] = 0;
+                    bvar[j] = -1;
+                    ph_row[j] = rows_band[rowof[j]];
+                } else {
+                    if (piv[j] != j) std::swap(rowof[j], rowof[piv[j]]);
+                    if (bvar[j] < 0) ph_row[j] = rows_band[j];
+                }
             }
-            if (nrep)
-                for (auto &rowlist : b21)
-                    rowlist.erase(std::remove_if(rowlist.begin(), rowlist.end(), [&](const std::pair<int32_t, double> &e) { return rep[e.first] != 0; }),
-                                  rowlist.end());
         }
-        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: band LU done at %.1f ms\n", epochs, now() - t_begin);
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: band LU done at %.1f ms (kl=%d ku=%d, %lld columns set aside)\n", epochs, now() - t_begin, kl, ku, (long long)nrep);
+        // ---------------------------------------------------------------- the border: as many columns as rows
+        auto untrack = [&](int64_t v) { tracked.erase(std::remove(tracked.begin(), tracked.end(), static_cast<int32_t>(v)), tracked.end()); };
+        std::vector<int64_t> bcol;
+        for (int64_t v = 0; v < NV; ++v)
+            if (is_basic[v] && !placed[v]) bcol.push_back(v);
+        int64_t h = 0;
+        for (int64_t p = 0; p < m1; ++p) h += bvar[p] < 0;
+        {
+            // too few columns for the border rows (or a border beyond the dense LU): placeholders become their row's own
+            // logical, then the dense rows' logicals fill in; too many: the surplus leaves the basis (superbasic)
+            std::vector<int32_t> gone;
+            for (int64_t p = 0; p < m1 && (static_cast<int64_t>(bcol.size()) < ndr + h || ndr + h > MAX_NB); ++p) {
+                if (bvar[p] >= 0) continue;
+                const int64_t w = n + ph_row[p];
+                if (is_basic[w]) continue;
+                bvar[p] = w;
+                is_basic[w] = 1;
+                placed[w] = 1;
+                gone.push_back(static_cast<int32_t>(w));
+                --h;
+            }
+            for (int64_t k = 0; k < ndr && static_cast<int64_t>(bcol.size()) < ndr + h; ++k) {
+                const int64_t w = n + rows_dense[k];
+                if (is_basic[w]) continue;
+                is_basic[w] = 1;
+                bcol.push_back(w);
+                gone.push_back(static_cast<int32_t>(w));
+            }
+            if (!gone.empty()) {
+                std::vector<uint8_t> g(static_cast<size_t>(NV), 0);
+                for (int32_t w : gone) g[w] = 1;
+                tracked.erase(std::remove_if(tracked.begin(), tracked.end(), [&](int32_t v) { return g[v] != 0; }), tracked.end());
+            }
+            if (guessed && !margin.empty()) // the surest columns first: a column the dense LU sets aside is one of the doubtful ones
+                std::sort(bcol.begin(), bcol.end(), [&](int64_t a, int64_t bb) { return margin[a] > margin[bb] || (margin[a] == margin[bb] && a < bb); });
+            else std::sort(bcol.begin(), bcol.end());
+            while (static_cast<int64_t>(bcol.size()) > ndr + h) {
+                const int64_t v = bcol.back();
+                bcol.pop_back();
+                is_basic[v] = 0;
+                tracked.push_back(static_cast<int32_t>(v));
+            }
+            if (static_cast<int64_t>(bcol.size()) != ndr + h || ndr + h > MAX_NB) {
+                sx_set_error("the border of the basis has %lld rows and %zu columns (at most %lld rows)", (long long)(ndr + h), bcol.size(), (long long)MAX_NB);
+                return SX_ERR_UNSUPPORTED;
+            }
+        }
+        const int64_t nb = ndr + h, mp = m1 + nb;
+        std::vector<int32_t> ph_pos;
+        for (int64_t p = 0; p < m1; ++p)
+            if (bvar[p] < 0) ph_pos.push_back(static_cast<int32_t>(p));
+        // ---- B21: the dense rows' entries in the band columns, one unit entry per placeholder row
+        SxBorderOps ops;
+        ops.ctx = ctx;
+        ops.m1 = m1;
+        ops.nb = nb;
+        ops.mp = mp;
+        ops.lu = lu;
+        ops.tiny = TB_TINY;
+        auto rows_to_dev = [&](const HostRows &R, int64_t nrows, bool with_list, SxRowsDev &out) -> int {
+            int64_t *dp = nullptr;
+            int32_t *di = nullptr, *dlist = nullptr;
+            double *dv = nullptr;
+            SX_TRY(edev.get(R.ptr.size(), &dp));
+            SX_TRY(edev.get(R.idx.size(), &di));
+            SX_TRY(edev.get(R.val.size(), &dv));
+            SX_TRY(up(s, dp, R.ptr));
+            SX_TRY(up(s, di, R.idx));
+            SX_TRY(up(s, dv, R.val));
+            if (with_list) {
+                SX_TRY(edev.get(R.list.size(), &dlist));
+                SX_TRY(up(s, dlist, R.list));
+            }
+            out.nrows = nrows;
+            out.ptr = dp;
+            out.idx = di;
+            out.val = dv;
+            out.list = dlist;
+            return SX_OK;
+        };
+        HostRows b21r, b21c, b12r, b12c;
+        if (nb > 0) {
+            std::vector<int32_t> er, ep;
+            std::vector<double> ev;
+            for (int64_t p = 0; p < m1; ++p) {
+                const int64_t v = bvar[p];
+                if (v < 0 || v >= n) continue;
+                for (int64_t k = cptr[v]; k < cptr[v + 1]; ++k)
+                    if (rowb[cidx[k]] < 0) {
+                        er.push_back(eqidx[cidx[k]] - static_cast<int32_t>(m1));
+                        ep.push_back(static_cast<int32_t>(p));
+                        ev.push_back(cval[k]);
+                    }
+            }
+            for (size_t t = 0; t < ph_pos.size(); ++t) {
+                er.push_back(static_cast<int32_t>(ndr + static_cast<int64_t>(t)));
+                ep.push_back(ph_pos[t]);
+                ev.push_back(1.0);
+            }
+            rows_from_triplets(nb, er, ep, ev, false, b21r);
+            rows_from_triplets(m1, ep, er, ev, true, b21c);
+            SX_TRY(rows_to_dev(b21r, nb, false, ops.b21_rows));
+            SX_TRY(rows_to_dev(b21c, static_cast<int64_t>(b21c.list.size()), true, ops.b21_cols));
+        }
+        // ---- the Schur complement, a block of border columns at a time: S[:, j] = (a2 - B21 B11^-1 a1) of column j
+        int64_t nrep2 = 0;
+        if (nb > 0) {
+            SX_TRY(sx_denselu_create_dev(ctx, nb, &dl));
+            double *Sa = nullptr;
+            int64_t Sld = 0;
+            SX_TRY(sx_denselu_matrix(dl, &Sa, &Sld));
+            const int64_t CH = std::max<int64_t>(16, std::min<int64_t>(std::min<int64_t>(nb, 1024), static_cast<int64_t>(2.0e9 / (8.0 * static_cast<double>(mp)))));
+            DevBufs sdev;
+            double *Wc = nullptr;
+            int32_t *d_bvars = nullptr;
+            SX_TRY(sdev.get(static_cast<size_t>(mp) * CH, &Wc));
+            SX_TRY(sdev.get(static_cast<size_t>(nb), &d_bvars));
+            std::vector<int32_t> bv32(bcol.begin(), bcol.end());
+            SX_TRY(up(s, d_bvars, bv32));
+            peak_bytes = std::max(peak_bytes, sizeof(double) * (static_cast<size_t>(mp) * CH + static_cast<size_t>(Sld) * nb));
+            for (int64_t c0 = 0; c0 < nb; c0 += CH) {
+                const int64_t kc = std::min<int64_t>(CH, nb - c0);
+                SX_HIP(hipMemsetAsync(Wc, 0, sizeof(double) * static_cast<size_t>(mp) * kc, s));
+                hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(kc)), dim3(TB_WG), 0, s, kc, d_bvars + c0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, Wc, mp);
+                SX_TRY(ops.ftran(Wc, kc, true, true));
+                SX_HIP(hipMemcpy2DAsync(Sa + static_cast<size_t>(c0) * Sld, sizeof(double) * Sld, Wc + m1, sizeof(double) * mp, sizeof(double) * nb,
+                                        static_cast<size_t>(kc), hipMemcpyDeviceToDevice, s));
+            }
+            SX_HIP(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: Schur complement (%lld rows: %lld dense, %lld placeholders) assembled at %.1f ms\n", epochs, (long long)nb, (long long)ndr, (long long)h, now() - t_begin);
+            std::vector<int32_t> rep2(static_cast<size_t>(nb)), perm2(static_cast<size_t>(nb));
+            SX_TRY(sx_denselu_factor_dev(dl, guessed ? tol_schur_guess : tol_schur_keep, &nrep2, rep2.data(), perm2.data()));
+            // a border column without a pivot leaves the basis (it stays in the tableau); what takes its place is the unit
+            // vector of the border row on its diagonal: a dense row's logical -- or, for a placeholder's row, the
+            // placeholder turns into its row's real logical (and the border column into its mirror image, a dummy)
+            // (all of them leave first: the logical a replaced column stands for may itself be a later border column that
+            //  the same elimination set aside)
+            for (int64_t j = 0; j < nb; ++j)
+                if (rep2[j]) {
+                    is_basic[bcol[j]] = 0;
+                    tracked.push_back(static_cast<int32_t>(bcol[j]));
+                }
+            for (int64_t j = 0; j < nb; ++j) {
+                if (!rep2[j]) continue;
+                const int64_t r = perm2[j];
+                int64_t w;
+                if (r < ndr) {
+                    w = n + rows_dense[r];
+                    bcol[j] = w;
+                } else {
+                    const int64_t p = ph_pos[static_cast<size_t>(r - ndr)];
+                    w = n + ph_row[p];
+                    bvar[p] = w;
+                    bcol[j] = -1;
+                }
+                if (is_basic[w]) {
+                    sx_set_error("internal: the repair of the Schur complement wants logical %lld twice", (long long)(w - n));
+                    return SX_ERR_UNSUPPORTED;
+                }
+                is_basic[w] = 1;
+                untrack(w);
+            }
+            if (trace) {
+                std::vector<double> dg(static_cast<size_t>(nb));
+                SX_HIP(hipMemcpy2D(dg.data(), sizeof(double), Sa, sizeof(double) * (Sld + 1), sizeof(double), static_cast<size_t>(nb), hipMemcpyDeviceToHost));
+                double mn = INFINITY;
+                int64_t c2 = 0, c4 = 0, c6 = 0;
+                for (double d : dg) {
+                    const double a = std::fabs(d);
+                    mn = std::min(mn, a);
+                    c2 += a < 1e-2;
+                    c4 += a < 1e-4;
+                    c6 += a < 1e-6;
+                }
+                fprintf(stderr, "[sx_crossover_band] epoch %d: Schur complement factored at %.1f ms (%lld columns set aside; smallest pivot %.2e, %lld / %lld / %lld below 1e-2 / 1e-4 / 1e-6)\n",
+                        epochs, now() - t_begin, (long long)nrep2, mn, (long long)c2, (long long)c4, (long long)c6);
+            }
+        }
+        ops.dl = dl;
+        // ---- B12: the border columns' entries in the band rows
+        if (nb > 0 && m1 > 0) {
+            std::vector<int32_t> ep, ej;
+            std::vector<double> ev;
+            for (int64_t j = 0; j < nb; ++j) {
+                const int64_t v = bcol[j];
+                if (v < 0) continue;
+                if (v >= n) {
+                    if (rowb[v - n] >= 0) {
+                        ep.push_back(rowb[v - n]);
+                        ej.push_back(static_cast<int32_t>(j));
+                        ev.push_back(1.0);
+                    }
+                    continue;
+                }
+                for (int64_t k = cptr[v]; k < cptr[v + 1]; ++k)
+                    if (rowb[cidx[k]] >= 0) {
+                        ep.push_back(rowb[cidx[k]]);
+                        ej.push_back(static_cast<int32_t>(j));
+                        ev.push_back(cval[k]);
+                    }
+            }
+            rows_from_triplets(m1, ep, ej, ev, true, b12r);
+            rows_from_triplets(nb, ej, ep, ev, false, b12c);
+            SX_TRY(rows_to_dev(b12r, static_cast<int64_t>(b12r.list.size()), true, ops.b12_rows));
+            SX_TRY(rows_to_dev(b12c, nb, false, ops.b12_cols));
+            ops.work_cols = std::max<int64_t>(1, std::min<int64_t>(128, static_cast<int64_t>(1.0e9 / (8.0 * static_cast<double>(m1)))));
+            SX_TRY(edev.get(static_cast<size_t>(m1) * ops.work_cols, &ops.work));
+        }
+        // ---- who is where
+        std::vector<int64_t> head(static_cast<size_t>(mp), -1);
+        for (int64_t p = 0; p < m1; ++p) head[p] = bvar[p];
+        for (int64_t j = 0; j < nb; ++j) head[m1 + j] = bcol[j];
         std::fill(vstat.begin(), vstat.end(), 0);
-        for (int64_t p = 0; p < m; ++p) {
+        int64_t n_basic = 0, n_dummy = 0;
+        for (int64_t p = 0; p < mp; ++p) {
+            if (head[p] < 0) {
+                ++n_dummy;
+                continue;
+            }
             if (vstat[head[p]] == 1) {
                 sx_set_error("internal: variable %lld covers two positions of the basis", (long long)head[p]);
-                return SX_ERR_INVALID;
+                return SX_ERR_UNSUPPORTED;
             }
             vstat[head[p]] = 1;
+            ++n_basic;
         }
-        // tracked columns: the picked ones that found no place, and those already tracked
+        if (n_basic != m) {
+            sx_set_error("internal: %lld basic variables for %lld rows", (long long)n_basic, (long long)m);
+            return SX_ERR_UNSUPPORTED;
+        }
+        for (int64_t v = 0; v < NV; ++v) is_basic[v] = vstat[v] == 1;
         std::vector<int32_t> varJ;
-        for (int64_t v = 0; v < NV; ++v)
-            if (pick[v] && vstat[v] != 1) {
-                vstat[v] = 2;
-                varJ.push_back(static_cast<int32_t>(v));
-            }
         for (int32_t v : tracked)
             if (vstat[v] == 0) {
                 vstat[v] = 2;
                 varJ.push_back(v);
             }
         int64_t nJ = static_cast<int64_t>(varJ.size());
-        if (capJ == 0) {
-            capJ = nJ + std::max<int64_t>(4096, nJ / 2);
+        // ---------------------------------------------------------------- this epoch's blocks: positions, tableau, eta file
+        const int nblk = static_cast<int>(gridof(mp));
+        double *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr, *d_vec = nullptr, *d_part = nullptr, *d_infpart = nullptr,
+               *d_eta = nullptr;
+        int32_t *d_head = nullptr, *d_blist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr, *d_eta_r = nullptr;
+        TbPart *d_rpart = nullptr;
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_xB));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_lB));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_uB));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_cB));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_g));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_vec));
+        SX_TRY(edev.get(static_cast<size_t>(mp), &d_head));
+        SX_TRY(edev.get(static_cast<size_t>(2 * nblk), &d_part));
+        SX_TRY(edev.get(static_cast<size_t>(nblk), &d_blist));
+        SX_TRY(edev.get(static_cast<size_t>(2 * nblk), &d_infpart));
+        SX_TRY(edev.get(static_cast<size_t>(nblk), &d_infoff));
+        SX_TRY(edev.get(static_cast<size_t>(TB_INFLIST), &d_inflist));
+        SX_TRY(edev.get(static_cast<size_t>(nblk), &d_rpart));
+        // basis changes before the basis is factored afresh (bounds the eta file and the drift of the tableau); a fresh
+        // factorisation keeps every basic variable (bordered form), so the file need not be long
+        int64_t EPOCH = std::min<int64_t>(20000, std::max<int64_t>(2 * nJ + 512, static_cast<int64_t>(16.0e9 / (8.0 * static_cast<double>(mp)))));
+        TbSlots sl;
+        {
             size_t free_b = 0, total_b = 0;
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (static_cast<double>(capJ) * m * 8.0 > 0.9 * static_cast<double>(free_b)) capJ = nJ + 1024;
-            if (static_cast<double>(capJ) * m * 8.0 > 0.95 * static_cast<double>(free_b)) {
-                sx_set_error("the tableau of %lld tracked columns over %lld rows does not fit the free device memory", (long long)capJ, (long long)m);
+            int64_t cap0 = nJ + std::max<int64_t>(256, nJ / 4);
+            if (static_cast<double>(TbSlots::bytes_for(mp, cap0)) > 0.6 * static_cast<double>(free_b)) cap0 = nJ + 16;
+            if (static_cast<double>(TbSlots::bytes_for(mp, cap0)) > 0.8 * static_cast<double>(free_b)) {
+                sx_set_error("the tableau of %lld tracked columns over %lld positions does not fit the free device memory", (long long)cap0, (long long)mp);
                 return SX_ERR_NOMEM;
             }
-            SX_TRY(dev.get(static_cast<size_t>(m) * capJ, &d_T));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_xJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_lJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_uJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_cJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_dJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_d1));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_rowbuf));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_varJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_statJ));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_s0));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_sbase));
-            SX_TRY(dev.get(static_cast<size_t>(TB_K) * capJ, &d_vbuf));
-            SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_pr));
-            SX_TRY(dev.get(static_cast<size_t>(TB_K), &d_gu));
-            SX_TRY(dev.get(static_cast<size_t>(capJ), &d_elist));
-            SX_TRY(dev.get(static_cast<size_t>(TB_EB) * capJ, &d_ebG));
-            SX_TRY(dev.get(static_cast<size_t>(TB_EB) * capJ, &d_ebS));
-            SX_TRY(dev.get(static_cast<size_t>(TB_EB) * TB_EB, &d_ebM));
-            // the eta file takes what is left (up to 20,000 basis changes)
+            SX_TRY(sl.reserve(s, mp, cap0, 0));
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (!getenv("SX_BAND_EPOCH"))
-                EPOCH = std::min<int64_t>(std::min<int64_t>(20000, 4 * nJ + 4096),
-                                          std::max<int64_t>(256, static_cast<int64_t>(0.8 * static_cast<double>(free_b) / (8.0 * static_cast<double>(m))) - 1));
-            SX_TRY(dev.get(static_cast<size_t>(m) * (EPOCH + 1), &d_eta));
-            SX_TRY(dev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
-        }
-        if (nJ > capJ) {
-            sx_set_error("the tracked columns (%lld) outgrew the tableau (%lld)", (long long)nJ, (long long)capJ);
-            return SX_ERR_NOMEM;
+            EPOCH = std::min<int64_t>(EPOCH, std::max<int64_t>(64, static_cast<int64_t>(0.5 * static_cast<double>(free_b) / (8.0 * static_cast<double>(mp))) - 1));
+            if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
+            SX_TRY(edev.get(static_cast<size_t>(mp) * (EPOCH + 1), &d_eta));
+            SX_TRY(edev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
+            peak_bytes = std::max(peak_bytes, TbSlots::bytes_for(mp, cap0) + sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1));
         }
         // ---------------------------------------------------------------- values: non-basic and tracked columns, right-hand side
         // logical of row i: s_i = b_i - (A x)_i for the tracked ones (their current value), 0 for the non-basic ones
@@ -1325,56 +1654,38 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         std::vector<double> hr;
         SX_TRY(down(s, hr, d_tmpm, static_cast<size_t>(m)));
         SX_HIP(hipStreamSynchronize(s));
-        std::vector<double> rp(static_cast<size_t>(m));
+        std::vector<double> rp(static_cast<size_t>(mp), 0.0); // (a placeholder's border row: 0)
         for (int64_t i = 0; i < m; ++i) rp[eqidx[i]] = hr[i] - xlog[i];
-        // dense rows in device form
-        std::vector<int64_t> b21ptr(static_cast<size_t>(ndr) + 1, 0);
-        std::vector<int32_t> b21pos;
-        std::vector<double> b21val;
-        for (int64_t k = 0; k < ndr; ++k) {
-            for (auto &e : b21[k]) {
-                b21pos.push_back(e.first);
-                b21val.push_back(e.second);
-            }
-            b21ptr[k + 1] = static_cast<int64_t>(b21pos.size());
-        }
-        int64_t *d_b21ptr = nullptr;
-        int32_t *d_b21pos = nullptr;
-        double *d_b21val = nullptr;
-        SX_TRY(edev.get(b21ptr.size(), &d_b21ptr));
-        SX_TRY(edev.get(b21pos.size(), &d_b21pos));
-        SX_TRY(edev.get(b21val.size(), &d_b21val));
-        SX_TRY(up(s, d_b21ptr, b21ptr));
-        SX_TRY(up(s, d_b21pos, b21pos));
-        SX_TRY(up(s, d_b21val, b21val));
-        // solve helper: position-space vectors through B0 (band part + dense rows), then the eta file
-        auto ftran_cols = [&](double *W, int64_t ncols, int64_t n_eta_now) -> int {
+        // solve helper: row-space columns through the bordered factors, then the eta file
+        auto ftran_cols = [&](double *W, int64_t ncols, int64_t n_eta_now, bool lp_columns) -> int {
             if (ncols == 0) return SX_OK;
-            if (lu) { // tableau columns are columns of A: a few entries each (TB_TINY: sx_bandlu_solve_sparse_dev)
-                if (ncols > 1 && !dense_solves) SX_TRY(sx_bandlu_solve_sparse_dev(lu, ncols, W, m, TB_TINY));
-                else SX_TRY(sx_bandlu_solve_dev(lu, 0, ncols, W, m));
-            }
-            if (ndr) hipLaunchKernelGGL(k_tb_dense_rows, dim3(gridof(ndr * ncols)), dim3(TB_WG), 0, s, ndr, ncols, d_b21ptr, d_b21pos, d_b21val, W, m, m1);
+            SX_TRY(ops.ftran(W, ncols, lp_columns));
             if (n_eta_now > 0) { // (what the tableau would drop anyway goes first: the list of an eta holds real entries only)
-                hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(m * ncols)), dim3(TB_WG), 0, s, m * ncols, W, TB_DROP);
+                hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(mp * ncols)), dim3(TB_WG), 0, s, mp * ncols, W, TB_DROP);
             }
             for (int64_t k0 = 0; k0 < n_eta_now; k0 += TB_EB) {
                 const int K = static_cast<int>(std::min<int64_t>(TB_EB, n_eta_now - k0));
-                hipLaunchKernelGGL(k_tb_etab_gather, dim3(gridof(std::max<int64_t>(TB_EB * ncols, TB_EB * TB_EB))), dim3(TB_WG), 0, s, m, ncols, W, d_eta,
-                                   d_eta_r, k0, K, d_ebG, d_ebM);
-                hipLaunchKernelGGL(k_tb_etab_solve, dim3(static_cast<unsigned>((ncols + 63) / 64)), dim3(64), 0, s, ncols, d_ebG, d_ebM, d_ebS, d_elist);
+                hipLaunchKernelGGL(k_tb_etab_gather, dim3(gridof(std::max<int64_t>(TB_EB * ncols, TB_EB * TB_EB))), dim3(TB_WG), 0, s, mp, ncols, W, d_eta,
+                                   d_eta_r, k0, K, sl.ebG, d_ebM);
+                hipLaunchKernelGGL(k_tb_etab_solve, dim3(static_cast<unsigned>((ncols + 63) / 64)), dim3(64), 0, s, ncols, sl.ebG, d_ebM, sl.ebS, sl.elist);
                 hipLaunchKernelGGL(k_tb_etab_apply, dim3(static_cast<unsigned>(std::min(nblk, 1024)), static_cast<unsigned>((ncols + TB_EC - 1) / TB_EC)),
-                                   dim3(TB_WG), 0, s, m, ncols, W, d_eta, d_eta_r, k0, K, d_ebS, d_elist);
+                                   dim3(TB_WG), 0, s, mp, ncols, W, d_eta, d_eta_r, k0, K, sl.ebS, sl.elist);
             }
             SX_HIP(hipGetLastError());
             return SX_OK;
         };
-        // ---- basic variables
+        // ---- basic variables (a dummy -- placeholder or mirror column -- is free, costs nothing and never leaves)
         {
-            std::vector<double> hlB(static_cast<size_t>(m)), huB(static_cast<size_t>(m)), hcB(static_cast<size_t>(m));
-            std::vector<int32_t> hhead(static_cast<size_t>(m));
-            for (int64_t p = 0; p < m; ++p) {
+            std::vector<double> hlB(static_cast<size_t>(mp)), huB(static_cast<size_t>(mp)), hcB(static_cast<size_t>(mp));
+            std::vector<int32_t> hhead(static_cast<size_t>(mp));
+            for (int64_t p = 0; p < mp; ++p) {
                 hhead[p] = static_cast<int32_t>(head[p]);
+                if (head[p] < 0) {
+                    hlB[p] = -INFINITY;
+                    huB[p] = INFINITY;
+                    hcB[p] = 0.0;
+                    continue;
+                }
                 hlB[p] = var_lo(head[p]);
                 huB[p] = var_up(head[p]);
                 hcB[p] = var_cost(head[p]);
@@ -1386,31 +1697,35 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             SX_TRY(up(s, d_xB, rp));
             SX_HIP(hipStreamSynchronize(s));
         }
-        SX_TRY(ftran_cols(d_xB, 1, 0));
+        SX_TRY(ftran_cols(d_xB, 1, 0, false));
         if (trace) { // how far the basic solution is from the point handed over (conditioning of the guessed basis)
             std::vector<double> t;
-            SX_TRY(down(s, t, d_xB, static_cast<size_t>(m)));
+            SX_TRY(down(s, t, d_xB, static_cast<size_t>(mp)));
             SX_HIP(hipStreamSynchronize(s));
-            double dev = 0.0, worst = 0.0;
-            int64_t ninf = 0;
-            for (int64_t p = 0; p < m; ++p) {
+            double devi = 0.0, worst = 0.0, dummy = 0.0;
+            int64_t ninf = 0, inf_bs = 0, inf_bl = 0, inf_border = 0, border_struct = 0;
+            for (int64_t j = 0; j < nb; ++j) border_struct += bcol[j] >= 0 && bcol[j] < n;
+            for (int64_t p = 0; p < mp; ++p) {
                 const int64_t v = head[p];
+                if (v < 0) {
+                    if (p < m1) dummy = std::max(dummy, std::fabs(t[p]));
+                    continue;
+                }
                 const double ref = v < n ? hx[v] : (hlt[v - n] ? std::max(hslack[v - n], 0.0) : 0.0);
-                dev = std::max(dev, std::fabs(t[p] - ref));
+                devi = std::max(devi, std::fabs(t[p] - ref));
                 const double vi = std::max(var_lo(v) - t[p], t[p] - var_up(v));
-                if (vi > feas_tol) ++ninf;
+                if (vi > feas_tol) {
+                    ++ninf;
+                    if (p >= m1) ++inf_border;
+                    else if (v < n) ++inf_bs;
+                    else ++inf_bl;
+                }
                 worst = std::max(worst, vi);
             }
-            // residual of the band solve itself: B11 t[0:m1] - rp[0:m1] (replaced columns are unit vectors)
-            std::vector<double> res(rp.begin(), rp.begin() + m1);
-            double rmax = 0.0, tmaxv = 0.0;
-            for (size_t e = 0; e < tval.size(); ++e) res[trow[e]] -= tval[e] * t[tcol[e]];
-            for (int64_t p = 0; p < m1; ++p) {
-                rmax = std::max(rmax, std::fabs(res[p]));
-                tmaxv = std::max(tmaxv, std::fabs(t[p]));
-            }
+            fprintf(stderr, "[sx_crossover_band] epoch %d: outside their bounds: %lld band columns, %lld band logicals, %lld border variables (the border holds %lld columns, %lld logicals)\n",
+                    epochs, (long long)inf_bs, (long long)inf_bl, (long long)inf_border, (long long)border_struct, (long long)(nb - border_struct));
             fprintf(stderr, "[sx_crossover_band] epoch %d: basic solution deviates from the point by at most %.3e; %lld basic variables outside their bounds (worst %.3e); "
-                            "band solve residual %.3e (|x| <= %.3e, %lld columns replaced)\n", epochs, dev, (long long)ninf, worst, rmax, tmaxv, (long long)nrep);
+                            "placeholders hold at most %.1e; %.1f ms\n", epochs, devi, (long long)ninf, worst, dummy, now() - t_begin);
         }
         // ---- tracked columns
         auto value_of = [&](int64_t v) { return v < n ? hx[v] : xlog[v - n]; };
@@ -1428,35 +1743,28 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 if (vx[t] > vl[t] && vx[t] < vu[t]) vs[t] = TB_SUP;
                 else vs[t] = (vx[t] >= vu[t] && vu[t] > vl[t]) ? TB_UPP : TB_LOW;
             }
-            SX_HIP(hipMemcpyAsync(d_varJ + s0, vars.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, s));
-            SX_HIP(hipMemcpyAsync(d_xJ + s0, vx.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
-            SX_HIP(hipMemcpyAsync(d_lJ + s0, vl.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
-            SX_HIP(hipMemcpyAsync(d_uJ + s0, vu.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
-            SX_HIP(hipMemcpyAsync(d_cJ + s0, vc.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
-            SX_HIP(hipMemcpyAsync(d_statJ + s0, vs.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.varJ + s0, vars.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.xJ + s0, vx.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.lJ + s0, vl.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.uJ + s0, vu.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.cJ + s0, vc.data(), sizeof(double) * k, hipMemcpyHostToDevice, s));
+            SX_HIP(hipMemcpyAsync(sl.statJ + s0, vs.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, s));
             SX_HIP(hipStreamSynchronize(s)); // (the staging vectors go out of scope)
             return SX_OK;
         };
         auto build_cols = [&](int64_t s0, int64_t k, int64_t n_eta_now) -> int {
             if (k == 0) return SX_OK;
-            double *W = d_T + static_cast<size_t>(s0) * m;
-            SX_HIP(hipMemsetAsync(W, 0, sizeof(double) * static_cast<size_t>(m) * k, s));
-            hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(k)), dim3(TB_WG), 0, s, k, d_varJ + s0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, W, m);
-            SX_TRY(ftran_cols(W, k, n_eta_now));
-            hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(m * k)), dim3(TB_WG), 0, s, m * k, W, 10.0 * TB_DROP);
+            double *W = sl.T + static_cast<size_t>(s0) * mp;
+            SX_HIP(hipMemsetAsync(W, 0, sizeof(double) * static_cast<size_t>(mp) * k, s));
+            hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(k)), dim3(TB_WG), 0, s, k, sl.varJ + s0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, W, mp);
+            SX_TRY(ftran_cols(W, k, n_eta_now, true));
+            hipLaunchKernelGGL(k_tb_drop, dim3(gridcap(mp * k)), dim3(TB_WG), 0, s, mp * k, W, 10.0 * TB_DROP);
             // reduced costs of the new columns under the current basis: d = c_J - c_B^T T
-            hipLaunchKernelGGL(k_tb_coldot, dim3(static_cast<unsigned>(k)), dim3(TB_WG), 0, s, m, W, d_cB, d_cJ + s0, d_dJ + s0);
+            hipLaunchKernelGGL(k_tb_coldot, dim3(static_cast<unsigned>(k)), dim3(TB_WG), 0, s, mp, W, d_cB, sl.cJ + s0, sl.dJ + s0);
             SX_HIP(hipGetLastError());
             return SX_OK;
         };
         SX_TRY(load_slots(0, varJ));
-        SX_HIP(hipMemsetAsync(d_s0, 0, sizeof(int32_t) * static_cast<size_t>(capJ), s));       // no pending update anywhere
-        SX_HIP(hipMemsetAsync(d_sbase, 0xFF, sizeof(int32_t) * static_cast<size_t>(capJ), s)); // (-1: every slot's base column is T's)
-        const TbPend pend{d_vbuf, d_pr, d_s0, d_sbase, capJ};
-        if (trace) {
-            SX_HIP(hipStreamSynchronize(s));
-            fprintf(stderr, "[sx_crossover_band] epoch %d: basic solution and slots done at %.1f ms\n", epochs, now() - t_begin);
-        }
         SX_TRY(build_cols(0, nJ, 0));
         if (trace) {
             SX_HIP(hipStreamSynchronize(s));
@@ -1470,35 +1778,38 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         SX_HIP(hipMemcpyAsync(d_st, &hst, sizeof(hst), hipMemcpyHostToDevice, s));
         SX_HIP(hipStreamSynchronize(s));
         if (trace)
-            fprintf(stderr, "[sx_crossover_band] epoch %d: kl=%d ku=%d, %lld rows covered by their logical, %lld columns replaced by the LU, %lld tracked columns "
-                            "(tableau capacity %lld = %.2f GB); %.1f ms so far\n", epochs, kl, ku, (long long)n_art, (long long)nrep, (long long)nJ, (long long)capJ,
-                    static_cast<double>(m) * capJ * 8e-9, now() - t_begin);
+            fprintf(stderr, "[sx_crossover_band] epoch %d: %lld positions (%lld band + %lld border, %lld dummies), %lld tracked columns (tableau capacity %lld = %.2f GB, "
+                            "eta file %lld = %.2f GB); %.1f ms so far\n", epochs, (long long)mp, (long long)m1, (long long)nb, (long long)n_dummy, (long long)nJ,
+                    (long long)sl.cap, static_cast<double>(mp) * sl.cap * 8e-9, (long long)EPOCH, static_cast<double>(mp) * (EPOCH + 1) * 8e-9, now() - t_begin);
         // ---------------------------------------------------------------- the simplex on the tracked columns
         auto one_pivot = [&]() {
-            hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
+            const TbPend pend{sl.vbuf, d_pr, sl.s0, sl.sbase, sl.cap};
+            hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, mp, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
             hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st, d_infoff);
-            hipLaunchKernelGGL(k_tb_inflist, dim3(nblk), dim3(TB_WG), 0, s, m, d_g, d_infpart, d_infoff, d_st, d_inflist);
-            hipLaunchKernelGGL(k_tb_gu, dim3(TB_K), dim3(TB_WG), 0, s, m, nblk, d_eta, d_g, d_inflist, d_st, pend, d_gu);
-            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, m, nblk, d_T, d_g, d_inflist, d_st, pend, d_gu, d_d1);
-            hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_d1, d_statJ, d_xJ, d_lJ, d_uJ, d_st);
-            hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, m, d_T, d_xB, d_lB, d_uB, d_st, d_eta, d_part, pend);
+            hipLaunchKernelGGL(k_tb_inflist, dim3(nblk), dim3(TB_WG), 0, s, mp, d_g, d_infpart, d_infoff, d_st, d_inflist);
+            hipLaunchKernelGGL(k_tb_gu, dim3(TB_K), dim3(TB_WG), 0, s, mp, nblk, d_eta, d_g, d_inflist, d_st, pend, d_gu);
+            hipLaunchKernelGGL(k_tb_price1, dim3(static_cast<unsigned>(nJ)), dim3(TB_WG), 0, s, mp, nblk, sl.T, d_g, d_inflist, d_st, pend, d_gu, sl.d1);
+            hipLaunchKernelGGL(k_tb_select, dim3(1), dim3(TB_WG), 0, s, nJ, sl.dJ, sl.d1, sl.statJ, sl.xJ, sl.lJ, sl.uJ, d_st);
+            hipLaunchKernelGGL(k_tb_ratio1, dim3(nblk), dim3(TB_WG), 0, s, mp, sl.T, d_xB, d_lB, d_uB, d_st, d_eta, d_part, pend);
             hipLaunchKernelGGL(k_tb_tmax, dim3(1), dim3(TB_WG), 0, s, nblk, d_part, d_st, d_blist);
-            hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
-            hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(TB_WG), 0, s, nblk, d_rpart, d_xJ, d_lJ, d_uJ, d_statJ, d_st);
-            hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, m, nJ, d_T, d_eta, d_st, pend, d_rowbuf);
-            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64))), dim3(TB_WG), 0, s, m, d_xB, d_eta, d_st, d_blist);
-            hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, d_dJ, d_rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, d_varJ, d_xJ, d_lJ, d_uJ,
-                               d_cJ, d_statJ, d_eta_r, d_st, d_vbuf, capJ, d_pr, d_s0, d_sbase);
+            hipLaunchKernelGGL(k_tb_ratio, dim3(nblk), dim3(TB_WG), 0, s, mp, d_xB, d_lB, d_uB, d_st, d_eta, d_rpart);
+            hipLaunchKernelGGL(k_tb_decide, dim3(1), dim3(TB_WG), 0, s, nblk, d_rpart, sl.xJ, sl.lJ, sl.uJ, sl.statJ, d_st);
+            hipLaunchKernelGGL(k_tb_rowcopy, dim3(gridof(nJ)), dim3(TB_WG), 0, s, mp, nJ, sl.T, d_eta, d_st, pend, sl.rowbuf);
+            hipLaunchKernelGGL(k_tb_update, dim3(static_cast<unsigned>(std::min(nblk, 64))), dim3(TB_WG), 0, s, mp, d_xB, d_eta, d_st, d_blist);
+            hipLaunchKernelGGL(k_tb_post, dim3(1), dim3(TB_WG), 0, s, nJ, sl.dJ, sl.rowbuf, d_head, d_xB, d_lB, d_uB, d_cB, sl.varJ, sl.xJ, sl.lJ, sl.uJ,
+                               sl.cJ, sl.statJ, d_eta_r, d_st, sl.vbuf, sl.cap, d_pr, sl.s0, sl.sbase);
         };
         auto fold = [&]() { // applies the pending batch when it is nearly full, or when the run has stopped
+            const TbPend pend{sl.vbuf, d_pr, sl.s0, sl.sbase, sl.cap};
             hipLaunchKernelGGL(k_tb_fold_begin, dim3(1), dim3(1), 0, s, d_st, 16);
             hipLaunchKernelGGL(k_tb_fold, dim3(static_cast<unsigned>(std::min(nblk, 128)), static_cast<unsigned>((nJ + TB_FJ - 1) / TB_FJ)), dim3(TB_WG), 0, s,
-                               m, nJ, d_T, d_eta, d_st, pend);
-            hipLaunchKernelGGL(k_tb_fold_end, dim3(gridof(nJ)), dim3(TB_WG), 0, s, nJ, d_st, d_s0, d_sbase);
+                               mp, nJ, sl.T, d_eta, d_st, pend);
+            hipLaunchKernelGGL(k_tb_fold_end, dim3(gridof(nJ)), dim3(TB_WG), 0, s, nJ, d_st, sl.s0, sl.sbase);
             hipLaunchKernelGGL(k_tb_fold_done, dim3(1), dim3(1), 0, s, d_st);
         };
         int rounds = 0;
         bool restart = false;
+        std::vector<double> hrc; // reduced costs of the structural columns under the last duals
         for (;;) {
             ++rounds;
             if (nJ > 0) {
@@ -1511,7 +1822,7 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                     if (hst.status != 0) break;
                 }
             } else { // nothing tracked: only the state of the basic variables decides the phase
-                hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, m, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
+                hipLaunchKernelGGL(k_tb_infeas, dim3(nblk), dim3(TB_WG), 0, s, mp, d_xB, d_lB, d_uB, d_st, d_g, d_infpart);
                 hipLaunchKernelGGL(k_tb_phase, dim3(1), dim3(TB_WG), 0, s, nblk, d_infpart, d_st, d_infoff);
                 SX_HIP(hipMemcpyAsync(&hst, d_st, sizeof(hst), hipMemcpyDeviceToHost, s));
                 SX_HIP(hipStreamSynchronize(s));
@@ -1529,28 +1840,18 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
             // ---- no tracked column prices out: duals, then every other column.  In phase 1 the cost is the
             //      infeasibility's (g on the basic variables, nothing elsewhere)
             const bool ph1 = hst.phase == 1;
-            SX_HIP(hipMemcpyAsync(d_vec, ph1 ? d_g : d_cB, sizeof(double) * static_cast<size_t>(m), hipMemcpyDeviceToDevice, s));
+            SX_HIP(hipMemcpyAsync(d_vec, ph1 ? d_g : d_cB, sizeof(double) * static_cast<size_t>(mp), hipMemcpyDeviceToDevice, s));
             const int etg = std::min(nblk, 64);
             for (int64_t k = hst.n_eta - 1; k >= 0; --k) {
-                const double *al = d_eta + static_cast<size_t>(k) * m;
-                hipLaunchKernelGGL(k_tb_eta_t_part, dim3(static_cast<unsigned>(etg)), dim3(TB_WG), 0, s, m, d_vec, al, d_eta_r, k, d_part);
+                const double *al = d_eta + static_cast<size_t>(k) * mp;
+                hipLaunchKernelGGL(k_tb_eta_t_part, dim3(static_cast<unsigned>(etg)), dim3(TB_WG), 0, s, mp, d_vec, al, d_eta_r, k, d_part);
                 hipLaunchKernelGGL(k_tb_eta_t_fin, dim3(1), dim3(1), 0, s, etg, d_vec, al, d_eta_r, k, d_part);
             }
-            std::vector<double> hv;
-            SX_TRY(down(s, hv, d_vec, static_cast<size_t>(m)));
-            SX_HIP(hipStreamSynchronize(s));
-            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: eta file transposed (%lld etas) by %.1f ms\n", rounds, (long long)hst.n_eta, now() - t_begin);
-            // B0^T y = v:  y2 = v2;  B11^T y1 = v1 - B21^T y2
-            for (int64_t k = 0; k < ndr; ++k) {
-                const double y2 = hv[m1 + k];
-                if (y2 != 0.0)
-                    for (int64_t e = b21ptr[k]; e < b21ptr[k + 1]; ++e) hv[b21pos[e]] -= b21val[e] * y2;
-            }
-            SX_HIP(hipMemcpyAsync(d_vec, hv.data(), sizeof(double) * static_cast<size_t>(m), hipMemcpyHostToDevice, s));
-            if (lu) SX_TRY(sx_bandlu_solve_dev(lu, 1, 1, d_vec, m));
+            SX_TRY(ops.btran(d_vec)); // B_aug^T y = v: position space in, row space out
             std::vector<double> yeq;
-            SX_TRY(down(s, yeq, d_vec, static_cast<size_t>(m)));
+            SX_TRY(down(s, yeq, d_vec, static_cast<size_t>(mp)));
             SX_HIP(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: duals (eta file of %lld, transposed solves) by %.1f ms\n", rounds, (long long)hst.n_eta, now() - t_begin);
             for (int64_t i = 0; i < m; ++i) hy[i] = yeq[eqidx[i]];
             // reduced costs of all structural columns with these duals (the K1 walk): rc = c' - A^T y
             SX_HIP(hipMemcpyAsync(d_tmpm, hy.data(), sizeof(double) * static_cast<size_t>(m), hipMemcpyHostToDevice, s));
@@ -1560,17 +1861,17 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 cost = d_tmpn;
             }
             SX_TRY(sx_score_columns_dev(ctx, A, d_tmpm, cost, nullptr, nullptr, nullptr, 0.0, d_rc, nullptr));
-            std::vector<double> hrc;
             SX_TRY(down(s, hrc, d_rc, static_cast<size_t>(n)));
             // who is where now
             std::vector<int32_t> hh, hvarJ, hstatJ;
-            SX_TRY(down(s, hh, d_head, static_cast<size_t>(m)));
-            SX_TRY(down(s, hvarJ, d_varJ, static_cast<size_t>(nJ)));
-            SX_TRY(down(s, hstatJ, d_statJ, static_cast<size_t>(nJ)));
+            SX_TRY(down(s, hh, d_head, static_cast<size_t>(mp)));
+            SX_TRY(down(s, hvarJ, sl.varJ, static_cast<size_t>(nJ)));
+            SX_TRY(down(s, hstatJ, sl.statJ, static_cast<size_t>(nJ)));
             SX_HIP(hipStreamSynchronize(s));
-            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: duals and reduced costs by %.1f ms\n", rounds, now() - t_begin);
+            if (trace) fprintf(stderr, "[sx_crossover_band]   round %d: reduced costs by %.1f ms\n", rounds, now() - t_begin);
             std::fill(vstat.begin(), vstat.end(), 0);
-            for (int64_t p = 0; p < m; ++p) vstat[hh[p]] = 1;
+            for (int64_t p = 0; p < mp; ++p)
+                if (hh[p] >= 0) vstat[hh[p]] = 1;
             for (int64_t t = 0; t < nJ; ++t) vstat[hvarJ[t]] = 2;
             std::vector<std::pair<double, int32_t>> viol;
             for (int64_t j = 0; j < n; ++j) {
@@ -1589,12 +1890,12 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
                 break;
             }
             std::sort(viol.begin(), viol.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &bb) { return a.first > bb.first || (a.first == bb.first && a.second < bb.second); });
-            const int64_t room = capJ - nJ;
-            if (room <= 0) {
-                hst.status = 3;
-                break;
+            const int64_t take = std::min<int64_t>(static_cast<int64_t>(viol.size()), 2048);
+            if (nJ + take > sl.cap) { // (nothing is pending here: the run stopped, its batch was folded)
+                const int rc_ = sl.reserve(s, mp, nJ + take + std::max<int64_t>(256, nJ / 2), nJ);
+                if (rc_ != SX_OK) return rc_;
+                peak_bytes = std::max(peak_bytes, 2 * TbSlots::bytes_for(mp, nJ) + sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1));
             }
-            const int64_t take = std::min<int64_t>(static_cast<int64_t>(viol.size()), std::min<int64_t>(room, 2048));
             std::vector<int32_t> add(static_cast<size_t>(take));
             for (int64_t t = 0; t < take; ++t) add[t] = viol[t].second;
             for (int32_t v : add)
@@ -1611,26 +1912,29 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         // ---------------------------------------------------------------- the epoch's end state -> host
         std::vector<int32_t> hh, hvarJ, hstatJ;
         std::vector<double> hxb, hxJ;
-        SX_TRY(down(s, hh, d_head, static_cast<size_t>(m)));
-        SX_TRY(down(s, hxb, d_xB, static_cast<size_t>(m)));
-        SX_TRY(down(s, hvarJ, d_varJ, static_cast<size_t>(nJ)));
-        SX_TRY(down(s, hstatJ, d_statJ, static_cast<size_t>(nJ)));
-        SX_TRY(down(s, hxJ, d_xJ, static_cast<size_t>(nJ)));
+        SX_TRY(down(s, hh, d_head, static_cast<size_t>(mp)));
+        SX_TRY(down(s, hxb, d_xB, static_cast<size_t>(mp)));
+        SX_TRY(down(s, hvarJ, sl.varJ, static_cast<size_t>(nJ)));
+        SX_TRY(down(s, hstatJ, sl.statJ, static_cast<size_t>(nJ)));
+        SX_TRY(down(s, hxJ, sl.xJ, static_cast<size_t>(nJ)));
         SX_HIP(hipStreamSynchronize(s));
         tot_iters += hst.iters;
         tot_pivots += hst.pivots;
         tot_flips += hst.flips;
         tot_degen += hst.degen;
-        std::fill(pick.begin(), pick.end(), 0);
+        std::fill(is_basic.begin(), is_basic.end(), 0);
         std::fill(vstat.begin(), vstat.end(), 0);
         tracked.clear();
         viol_max = 0.0;
-        for (int64_t p = 0; p < m; ++p) {
+        prev_pos.assign(static_cast<size_t>(m1), -1);
+        for (int64_t p = 0; p < mp; ++p) {
             const int64_t v = hh[p];
-            pick[v] = 1;
+            if (v < 0) continue;
+            is_basic[v] = 1;
             vstat[v] = 1;
             viol_max = std::max(viol_max, std::max(var_lo(v) - hxb[p], hxb[p] - var_up(v)));
             if (v < n) hx[v] = hxb[p];
+            if (p < m1 && v == head[p]) prev_pos[p] = v;
         }
         for (int64_t t = 0; t < nJ; ++t) {
             const int64_t v = hvarJ[t];
@@ -1646,6 +1950,33 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
         if ((hst.status == 4 || hst.status == 2) && bad_epochs < 2 && tot_iters < max_iter) { // a tiny pivot / a ray that should not be: fresh factors first
             ++bad_epochs;
             continue;
+        }
+        if (hst.status == 1) {
+            // ---- the vertex against A itself before it is called optimal: x_B was only ever updated, y came through the eta
+            //      file -- row residuals of x (one K2 walk) and the reduced costs of the basic columns (they are in hrc).
+            //      Beyond the tolerances: factor the current basis afresh and go on from there (twice at most)
+            SX_TRY(up(s, d_tmpn, hx));
+            SX_TRY(sx_score_rows_dev(ctx, A, d_tmpn, b, nullptr, 0.0, d_tmpm, nullptr));
+            SX_TRY(down(s, hslack, d_tmpm, static_cast<size_t>(m)));
+            SX_HIP(hipStreamSynchronize(s));
+            resid_max = 0.0;
+            double rc_basic = 0.0;
+            for (int64_t i = 0; i < m; ++i) {
+                const double sc = 1.0 + std::fabs(hb[i]);
+                const double r = hlt[i] ? std::max(-hslack[i], 0.0) : std::fabs(hslack[i]);
+                resid_max = std::max(resid_max, r / sc);
+            }
+            if (static_cast<int64_t>(hrc.size()) == n)
+                for (int64_t j = 0; j < n; ++j)
+                    if (vstat[j] == 1) rc_basic = std::max(rc_basic, std::fabs(hrc[j]) / (1.0 + std::fabs(hc[j])));
+            if (trace) fprintf(stderr, "[sx_crossover_band] check of the vertex: row residual %.2e (relative), reduced costs of basic columns %.2e\n", resid_max, rc_basic);
+            if (resid_max > 10.0 * feas_tol || rc_basic > 10.0 * opt_tol) {
+                if (check_epochs < 2 && tot_iters < max_iter) {
+                    ++check_epochs;
+                    continue;
+                }
+                final_status = 4;
+            }
         }
         break;
     }
@@ -1664,12 +1995,20 @@ SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *
     result->status = final_status == 1 ? 0 : (final_status == 101 ? 1 : final_status);
     result->iters = tot_iters;
     result->phase1_iters = added_total;
-    result->warm_start_used = 1;
+    result->warm_start_used = vbasis_in ? 1 : 0;
     result->obj = obj;
-    result->max_violation = viol_max > 0 ? viol_max : 0.0;
+    result->max_violation = std::max(viol_max > 0 ? viol_max : 0.0, resid_max);
     if (trace)
         fprintf(stderr, "[sx_crossover_band] done: status %lld, %lld iterations (%lld pivots, %lld flips, %lld of no length) in %d epochs, %lld columns added by "
-                        "pricing, objective %.12e, max violation %.2e, %.1f ms\n", (long long)result->status, tot_iters, tot_pivots, tot_flips, tot_degen, epochs,
-                (long long)added_total, obj, result->max_violation, now() - t_begin);
+                        "pricing, objective %.12e, max violation %.2e, largest blocks %.2f GB, %.1f ms\n", (long long)result->status, tot_iters, tot_pivots, tot_flips,
+                tot_degen, epochs, (long long)added_total, obj, result->max_violation, static_cast<double>(peak_bytes) * 1e-9, now() - t_begin);
     return SX_OK;
+}
+
+SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                 const double *u, const uint8_t *row_is_lt, const double *x_start, int64_t max_iter,
+                                 double feas_tol, double opt_tol, double *x_out, double *y_out, int8_t *vbasis_out,
+                                 int8_t *cbasis_out, sx_simplex_result *result) {
+    return sx_crossover_band_basis_dev(ctx, A, b, c, l, u, row_is_lt, x_start, nullptr, nullptr, max_iter, feas_tol, opt_tol, x_out, y_out,
+                                       vbasis_out, cbasis_out, result);
 }

@@ -184,6 +184,9 @@ int64_t sx_sort_blocks(int64_t n);
 int sx_sort_pairs(sx_ctx *ctx, int64_t n, uint64_t *const img[2], int32_t *const idx[2], int64_t *hist, int64_t *offs,
                   int nbytes, int *cur_out);
 
+// band LU (sx_bandlu.hip): does sx_bandlu_create_dev take these widths?  (the sparse crossover asks before it builds a band)
+bool sx_bandlu_supports(int kl, int ku);
+
 // dense LU (sx_denselu.hip): the device matrix of a handle (column major, *ld doubles per column), for the module that fills it
 int sx_denselu_matrix(sx_denselu *h, double **a_dev, int64_t *ld);
 

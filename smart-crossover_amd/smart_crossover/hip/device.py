@@ -271,13 +271,14 @@ class Context:
         return res
 
     def crossover_band(self, A, b, c, l, u, row_is_lt, x_start, max_iter=0, feas_tol=1e-9, opt_tol=1e-7, x=None, y=None,
-                       vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
-        """K16s (blocking): sparse crossover from the first-order point (band LU of the starting basis + tableau of
-        the tracked columns); raises NotImplementedError when the basis is no band matrix in the natural row order."""
+                       vbasis_out=None, cbasis_out=None, vbasis_in=None, cbasis_in=None) -> "_l.SimplexResult":
+        """K16s (blocking): sparse crossover from the first-order point -- or, with ``vbasis_in`` / ``cbasis_in``, from a given
+        basis (the warm-started final solve) -- on a bordered band factorisation + a tableau of the tracked columns; raises
+        NotImplementedError when the basis is no band matrix the band LU takes."""
         res = _l.SimplexResult()
-        _l.check(self._lib.sx_crossover_band_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt),
-                                                 _ptr(x_start), int(max_iter), float(feas_tol), float(opt_tol), _ptr(x), _ptr(y),
-                                                 _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
+        _l.check(self._lib.sx_crossover_band_basis_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt),
+                                                       _ptr(x_start), _ptr(vbasis_in), _ptr(cbasis_in), int(max_iter), float(feas_tol),
+                                                       float(opt_tol), _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
 
     def net_simplex(self, A, b, c, l, u, vbasis, cbasis, max_iter=0, feas_tol=1e-7, opt_tol=1e-7, x=None, y=None,

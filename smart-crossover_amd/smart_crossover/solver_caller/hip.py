@@ -1,23 +1,25 @@
-"""``HipCaller``: the device simplex of libsxhip.so (kernel group K16) behind the ``SolverCaller``
+"""``HipCaller``: the device solvers of libsxhip.so (kernel groups K16*) behind the ``SolverCaller``
 seam -- ``solver="HIP"`` in ``solve_lp`` / ``solve_mcf`` / ``solve_ot`` / ``network_crossover``.
 
 It serves the *simplex family* of methods ('default', 'simplex', 'primal_simplex', 'dual_simplex',
-'network_simplex' all run the bounded primal simplex) with Gurobi-style warm bases, i.e. the
-re-solves the crossover algorithms issue with a warm start (lp_methods/algorithms.py:69-74,
-network_methods/net_manager.py:222,468).
+'network_simplex') with Gurobi-style warm bases, i.e. the re-solves the crossover algorithms issue with a warm
+start (lp_methods/algorithms.py:69-74, network_methods/net_manager.py:222,468): network sub-problems go to the dual /
+primal network simplex (K16d / K16n), general LPs from ``BAND_MIN_ROWS`` rows on to the sparse crossover started from
+the given basis (K16s: bordered band factorisation of that very basis, ``sx_crossover_band_basis_dev``), everything
+else -- and whatever K16s refuses -- to the bounded primal simplex on a dense inverse (K16, 8 m^2 bytes: about 1.7e5
+rows on an empty MI355X).
 
-'barrier' with crossover -- the re-solve of the perturbed sub-problem, lp_methods/algorithms.py:50-54 --
-is served too, by a substitute: the reference's solvers run an interior-point method plus their own
-crossover there and ignore the warm start they are handed (quirk Q6); all the caller consumes is the optimal
-*vertex* and its basis, and the perturbed LP has a unique one.  The device has no interior-point method, so it
-takes the interior point it is handed (``crash_from_warm_start``: ``solve_problem`` passes the warm start
-on to backends that ask for it), turns it into a crash basis -- columns strictly between their bounds and
-slacks of inactive rows basic -- and starts the primal simplex AT that point (``sx_simplex_crossover_dev``:
-the columns that find no basis row stay superbasic at their interior value and are pushed out one pivot at a
-time, which is what a crossover does).  'barrier' *without* crossover (the initial solve, whose output is the interior point itself) is not
-available: pair the device with a barrier-capable backend through the composite name
-``"<barrier backend>+HIP"`` (e.g. ``"HGS+HIP"``).  Size limit: the dense basis inverse (8 m^2 bytes) must fit
-the free HBM, i.e. about 1.7e5 rows on an empty MI355X.
+'barrier' with crossover -- the re-solve of the perturbed sub-problem, lp_methods/algorithms.py:50-54 -- is served
+too, by a substitute: the reference's solvers run an interior-point method plus their own crossover there and ignore
+the warm start they are handed (quirk Q6); all the caller consumes is the optimal *vertex* and its basis, and the
+perturbed LP has a unique one.  The device takes the interior point it is handed (``crash_from_warm_start``:
+``solve_problem`` passes the warm start on to backends that ask for it), carries it towards the perturbed optimum by a
+first-order stage (K16p, ``sx_pdlp_dev``) and crosses over from there: K16s from ``BAND_MIN_ROWS`` rows on (basis guessed
+from the margins of the point, bordered band factorisation, tableau of the columns that can still move), the dense
+K16 (``sx_simplex_crossover_dev`` from a crash basis: columns strictly between their bounds and slacks of inactive rows
+basic, the rest superbasic) below that size or when K16s answers "unsupported".  'barrier' *without* crossover (the
+initial solve, whose output is the interior point itself) is not available: pair the device with a barrier-capable
+backend through the composite name ``"<barrier backend>+HIP"`` (e.g. ``"HGS+HIP"``).
 """
 from __future__ import annotations
 
@@ -32,6 +34,7 @@ import scipy.sparse as sp
 from smart_crossover.formats import GeneralLP, StandardLP
 from smart_crossover.output import Basis
 from smart_crossover.solver_caller.caller import SolverCaller, SolverSettings
+from smart_crossover.hip.lib import SxError as _SxError
 
 _STATUS = {0: "OPTIMAL", 1: "INFEASIBLE", 2: "UNBOUNDED"}
 
@@ -202,14 +205,7 @@ class HipCaller(SolverCaller):
                 self._warm_point = (d_px.download(), d_py.download())
                 self.pdlp_seconds = time.perf_counter() - t0
                 if to_band:      # ("dense": K16 whatever the size)
-                    try:
-                        self._res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_px, 0, 1e-7,
-                                                       float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb)
-                        self.solved_by = "crossover_band"
-                        if int(self._res.status) not in _STATUS and 8.0 * m * m < 1.2e11:
-                            self._res = None      # iteration limit / numerical trouble: the dense crossover may still do it
-                    except NotImplementedError:
-                        self._res = None          # no band structure: the dense crossover below
+                    self._res = self._band(ctx, dA, d_b, d_c, d_l, d_u, d_px, None, None, d_x, d_y, d_vb, d_cb)
             if self._res is None:
                 self._warm = self._crash_basis(ctx, dA)
             if self._warm is not None:          # crossover: start AT the interior point (superbasic columns)
@@ -217,6 +213,16 @@ class HipCaller(SolverCaller):
         if self._warm is not None and self._warm.vbasis.size == n and self._warm.cbasis.size == m:
             vb_in = ctx.to_device(np.clip(self._warm.vbasis, -3, 0).astype(np.int8))
             cb_in = ctx.to_device(np.clip(self._warm.cbasis, -1, 0).astype(np.int8))
+            mode = os.environ.get("SX_LP_CROSSOVER", "auto")
+            if (self._res is None and x_start is None and not self._network and self._session_holder is None
+                    and (mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS))):
+                # the warm-started simplex of the reference's last step (lp_methods/algorithms.py:69-74) at a size where the
+                # dense inverse is out of reach: the given basis is factored as it is (bordered band form), superbasic
+                # columns (-3) sit at the warm point's value
+                xs = self._warm_point[0] if self._warm_point is not None and np.asarray(self._warm_point[0]).size == n else np.zeros(n)
+                xs = np.clip(np.asarray(xs, dtype=np.float64), self._l, self._u)
+                xs = np.where(np.isfinite(xs), xs, 0.0)
+                self._res = self._band(ctx, dA, d_b, d_c, d_l, d_u, put(xs), vb_in, cb_in, d_x, d_y, d_vb, d_cb)
         session, col_ids = None, getattr(self, "_col_ids", None)
         holder = getattr(self, "_session_holder", None)
         if holder is not None and col_ids is not None:
@@ -256,13 +262,33 @@ class HipCaller(SolverCaller):
                                "use solver='HGS' for this instance")
         self._log_summary(self._runtime, int(self._res.iters))
 
+    def _band(self, ctx, dA, d_b, d_c, d_l, d_u, d_start, vb_in, cb_in, d_x, d_y, d_vb, d_cb):
+        """The sparse crossover (K16s); None when it does not apply or did not finish and the dense path may still do it."""
+        m = self._A.shape[0]
+        dense_fits = 8.0 * m * m < 1.2e11
+        try:
+            res = ctx.crossover_band(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), d_start, 0, 1e-7,
+                                     float(self.settings.optimalityTol), d_x, d_y, d_vb, d_cb, vbasis_in=vb_in, cbasis_in=cb_in)
+        except NotImplementedError:
+            return None                  # no band structure / border too large: the dense crossover
+        except (ValueError, MemoryError, _SxError) as exc:
+            if dense_fits:
+                return None
+            raise RuntimeError(f"the sparse crossover failed on a {m}-row problem ({exc}) and the dense basis inverse "
+                               "does not fit the device; use solver='HGS' for this instance") from exc
+        self.solved_by = "crossover_band"
+        if int(res.status) not in _STATUS and dense_fits:
+            return None                  # iteration limit / numerical trouble: the dense crossover may still do it
+        return res
+
     def run_default(self) -> None:
         self._solve()
 
     run_simplex = run_primal_simplex = run_dual_simplex = run_network_simplex = run_default
 
     def run_barrier(self) -> None:
-        """'barrier' + crossover: vertex and basis by the primal simplex from a crash basis (module docstring)."""
+        """'barrier' + crossover: first-order stage from the warm point, then the sparse (K16s) or dense (K16) crossover
+        to the vertex and its basis (module docstring)."""
         self._want_crash = True
         try:
             self._solve()

@@ -134,9 +134,12 @@ def dominant_band(n, kl, ku, seed, swaps):
 
 @pytest.mark.parametrize("swaps", [False, True])
 @pytest.mark.parametrize("n,kl,ku", [(6000, 40, 30), (20000, 117, 113)])
-def test_sparse_right_hand_sides(ctx, n, kl, ku, swaps):
-    """solve_sparse (panels without entries skipped): with tiny = 0 the plain solve's result bit for bit, with the
-    crossover's 1e-60 equal to 1e-50; right-hand sides with entries in one place, in two far apart, at both ends, none."""
+def test_sparse_right_hand_sides(ctx, monkeypatch, n, kl, ku, swaps):
+    """solve_sparse (panels without entries skipped): with tiny = 0 the result of the plain solve's SEQUENTIAL sweeps bit
+    for bit (SX_BANDLU_SEQ: up to 1,024 dense right-hand sides otherwise take the partitioned sweeps, which round
+    differently), with the crossover's 1e-60 equal to 1e-50; right-hand sides with entries in one place, in two far apart,
+    at both ends, none."""
+    monkeypatch.setenv("SX_BANDLU_SEQ", "1")
     A = dominant_band(n, kl, ku, 5, swaps)
     kl, ku = kl + int(swaps), ku + int(swaps)
     lu, rep, piv = factor(ctx, A, kl, ku)

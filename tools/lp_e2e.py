@@ -52,7 +52,7 @@ def main():
     t2 = time.perf_counter()
     p = caller.pdlp
     rec = {"which": which, "sub_shape": list(mgr.lp_sub.A.shape), "get_perturb_problem_s": t1 - t0, "resolve_s": t2 - t1,
-           "status": out.status, "gap_ok": bool(ok), "pivots": int(out.iter_count),
+           "status": out.status, "gap_ok": bool(ok), "pivots": int(out.iter_count or 0), "solved_by": getattr(caller, "solved_by", None),
            "pdlp": None if p is None else {"status": int(p.status), "iters": int(p.iters), "restarts": int(p.restarts),
                                            "pr": p.primal_residual, "du": p.dual_residual, "gap": p.gap,
                                            "omega": p.primal_weight, "seconds": getattr(caller, "pdlp_seconds", None)}}
