@@ -325,7 +325,48 @@ def crossover_lp_c5_end_to_end():
     get_perturb_problem + first-order stage + sparse crossover on the bordered band factorisation + gap test, host memory
     to host memory, one call in a warm process."""
     inst = workloads.netlib_lp(1_000_000, 10_000_000)
-    return _device_lp_crossover(inst, 1, "netlib_lp(1e6, 1e7) = config-5 size")
+    rec = _device_lp_crossover(inst, 1, "netlib_lp(1e6, 1e7) = config-5 size")
+    rec["scoring_on_this_lp"] = _scoring_walks_on(inst)
+    return rec
+
+
+def _scoring_walks_on(inst, reps: int = 5):
+    """The three scoring walks (K1 score_columns, K2 score_rows, K10 price) on THIS instance's matrix -- the same LP the
+    crossover leg above re-solves -- so that both halves of BASELINE's metric are quoted on one config-5 workload (the
+    headline scoring step runs on workloads.lp_shard, a kernel workload whose (x, y) is no consistent pair).  HIP events
+    on the library's stream, algorithmic bytes as in SURVEY.md 8(d)."""
+    from smart_crossover.hip import default_context
+    ctx = default_context()
+    m, n = inst.A.shape
+    dA = ctx.matrix(inst.A)
+    d = {k: ctx.to_device(getattr(inst, k)) for k in ("b", "c", "l", "u", "x", "y")}
+    vb = ctx.to_device(np.where(inst.x - inst.l < 1e-6, -1, np.where(inst.u - inst.x < 1e-6, -2, 0)).astype(np.int8))
+    s_d, code = ctx.empty(n, np.float64), ctx.empty(n, np.uint8)
+    s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
+    price = ctx.empty(24, np.uint8)
+    t = {"k_score_columns": [], "k_score_rows": [], "k_price": []}
+    for i in range(2 + reps):
+        ctx.marker(0)
+        ctx.score_columns(dA, d["y"], d["c"], d["x"], d["l"], d["u"], 1e-3, s_d, code)
+        ctx.marker(1)
+        ctx.score_rows(dA, d["x"], d["b"], d["y"], 1e-3, s_p, flag)
+        ctx.marker(2)
+        ctx.price(dA, d["y"], d["c"], vb, 1e-6, None, price)
+        ctx.marker(3)
+        ctx.sync()
+        if i >= 2:
+            for k, name in enumerate(t):
+                t[name].append(ctx.marker_elapsed(k, k + 1))
+    nnz = int(inst.A.nnz)
+    algo = {"k_score_columns": 12 * nnz + 49 * n + 8 * m, "k_score_rows": 12 * nnz + 8 * n + 33 * m, "k_price": 12 * nnz + 17 * n + 8 * m}
+    out = {"workload": f"netlib_lp {m} rows x {n} columns, {nnz} entries (1 % linking rows at the head)",
+           "row_layout": "column-blocked" if dA.rowblock() is not None else "plain walk (auto rule)"}
+    for name, ms in t.items():
+        avg = float(np.mean(ms))
+        out[name] = {"avg_kernel_ms": avg, "algorithmic_bytes": int(algo[name]), "achieved_GBps": algo[name] / avg / 1e6,
+                     "frac_of_hbm_peak": algo[name] / avg / 1e6 / HBM_PEAK_GBS, "columns_per_s": n / avg * 1e3}
+    dA.free()
+    return out
 
 
 def crossover_lp_c5():

@@ -112,6 +112,15 @@ __device__ __forceinline__ double tb_block_sum(double v, double *sm) {
     return r;
 }
 
+// dst[:, dest[s]] = src[:, s]  (rows x gridDim.y columns)
+__global__ __launch_bounds__(TB_WG) void k_tb_copy_cols(int64_t rows, const double *__restrict__ src, int64_t lds_, const int32_t *__restrict__ dest,
+                                                        double *__restrict__ dst, int64_t ldd) {
+    const int64_t sc = blockIdx.y;
+    const double *a = src + static_cast<size_t>(sc) * lds_;
+    double *o = dst + static_cast<size_t>(dest[sc]) * ldd;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; r < rows; r += static_cast<int64_t>(gridDim.x) * TB_WG) o[r] = a[r];
+}
+
 // entries below the drop tolerance -> exact zeros (what the pivots skip)
 // (grid-stride: a launch carries fewer than 2^32 work-items, a tableau has more entries than that)
 __global__ __launch_bounds__(TB_WG) void k_tb_drop(int64_t total, double *__restrict__ W, double tol) {
@@ -1196,10 +1205,14 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
     std::vector<int64_t> prev_pos;                          // band position -> the variable that sat there and never moved
     double viol_max = 0.0, resid_max = 0.0;
     size_t peak_bytes = 0;
+    bool strict_next = false, strict_tried = false;
 
     for (;;) {
         ++epochs;
-        const bool guessed = epochs == 1 && !vbasis_in; // the basic set is a guess from the margins of the point
+        // the basic set is a guess from the margins of the point -- or a given basis whose basic solution turned out far
+        // outside the bounds (below): the LUs then set aside what is all but dependent
+        const bool guessed = (epochs == 1 && !vbasis_in) || strict_next;
+        strict_next = false;
         DevBufs edev; // this epoch's device arrays
         // ---------------------------------------------------------------- columns to rows: who sits on which band row
         // Every band row gets at most ONE variable, whose position is the row's: a variable that sat there in the last
@@ -1278,6 +1291,72 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                     placed[e.var] = 1;
                 }
         }
+        // ---------------------------------------------------------------- blocks: the band cut at SEPARATORS
+        // A panel of the band LU is a chain of 32 dependent column steps on one workgroup (53 us at kl + ku = 230), a band of
+        // 1e5 rows 3,100 of them in a row.  Cut every RL + W positions: W = max(kl, ku) positions (rows AND the columns matched
+        // to them) go to the border as separators -- no column left of a separator reaches a row right of it, or the other way
+        // round -- so the P blocks between them are independent band matrices, factored side by side
+        // (sx_bandlu_factor_blocks_dev; identity padding of kl + ku + 32 positions keeps their memory apart).  The Schur
+        // complement grows by (P - 1) W rows.
+        const int64_t m1_all = m1;
+        int64_t P = 1, RL = m1_all, Wsep = 0, PAD = 0;
+        {
+            int kl0 = 0, ku0 = 0;
+            for (int64_t p = 0; p < m1_all; ++p) {
+                const int64_t v = bvar[p];
+                if (v < 0 || v >= n) continue;
+                for (int64_t k = cptr[v]; k < cptr[v + 1]; ++k) {
+                    const int32_t ib = rowb[cidx[k]];
+                    if (ib >= 0) {
+                        kl0 = std::max<int>(kl0, ib - static_cast<int>(p));
+                        ku0 = std::max<int>(ku0, static_cast<int>(p) - ib);
+                    }
+                }
+            }
+            const int64_t w = std::max(kl0, ku0), pad = ((kl0 + ku0 + 32 + 31) / 32) * 32;
+            int64_t want = getenv("SX_BAND_BLOCKS") ? atoll(getenv("SX_BAND_BLOCKS")) : std::min<int64_t>(32, m1_all / 8192);
+            while (want > 1) { // (2,048 rows of the border are left to placeholders and columns without a row)
+                const int64_t rl = ((m1_all - (want - 1) * w) / want) / 32 * 32;
+                if (w > 0 && rl >= 4 * pad && ndr + (want - 1) * w + 2048 <= MAX_NB) break;
+                --want;
+            }
+            if (want > 1) {
+                P = want;
+                Wsep = w;
+                PAD = pad;
+                RL = ((m1_all - (P - 1) * w) / P) / 32 * 32;
+            }
+        }
+        const int64_t RL_last = m1_all - (P - 1) * (RL + Wsep), stride = RL + PAD;
+        const int64_t m1e = (P - 1) * stride + RL_last, nsep = (P - 1) * Wsep;
+        std::vector<int64_t> bvar_e(static_cast<size_t>(m1e), -2); // (-2: padding, -1: placeholder)
+        std::vector<int32_t> posrow_e(static_cast<size_t>(m1e), -1), old_of_new(static_cast<size_t>(m1e), -1), rows_dense_e(rows_dense);
+        std::vector<int32_t> rowb_e(static_cast<size_t>(m), -1), eqidx_e(static_cast<size_t>(m), 0);
+        rows_dense_e.resize(static_cast<size_t>(ndr + nsep));
+        for (int64_t p = 0; p < m1_all; ++p) {
+            const int64_t b = std::min<int64_t>(p / (RL + Wsep), P - 1), off = p - b * (RL + Wsep);
+            const int32_t row = rows_band[p];
+            if (b < P - 1 && off >= RL) { // a separator: its row joins the dense rows, its column goes to the border
+                rows_dense_e[static_cast<size_t>(ndr + b * Wsep + off - RL)] = row;
+                if (bvar[p] >= 0) placed[bvar[p]] = 0;
+                continue;
+            }
+            const int64_t np = b * stride + off;
+            bvar_e[np] = bvar[p];
+            posrow_e[np] = row;
+            old_of_new[np] = static_cast<int32_t>(p);
+            rowb_e[row] = static_cast<int32_t>(np);
+            eqidx_e[row] = static_cast<int32_t>(np);
+        }
+        for (size_t k = 0; k < rows_dense_e.size(); ++k) eqidx_e[rows_dense_e[k]] = static_cast<int32_t>(m1e + static_cast<int64_t>(k));
+        int32_t *d_eqidx_e = nullptr;
+        SX_TRY(edev.get(eqidx_e.size(), &d_eqidx_e));
+        SX_TRY(up(s, d_eqidx_e, eqidx_e));
+        { // from here on the geometry is this epoch's: band positions with padding, dense rows with the separators' rows
+        const int64_t m1 = m1e, ndr = static_cast<int64_t>(rows_dense_e.size());
+        std::vector<int64_t> &bvar = bvar_e;
+        const std::vector<int32_t> &rows_band = posrow_e, &rows_dense = rows_dense_e, &rowb = rowb_e, &eqidx = eqidx_e;
+        const int32_t *d_eqidx = d_eqidx_e;
         // band triplets (a placeholder or a logical: the unit vector of the row), band widths
         std::vector<int32_t> trow, tcol;
         std::vector<double> tval;
@@ -1332,7 +1411,8 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             SX_TRY(up(s, d_tval, tval));
             SX_TRY(sx_bandlu_create_dev(ctx, m1, kl, ku, static_cast<int64_t>(tval.size()), d_trow, d_tcol, d_tval, &lu));
             std::vector<int32_t> rep(static_cast<size_t>(m1)), piv(static_cast<size_t>(m1));
-            SX_TRY(sx_bandlu_factor_dev(lu, guessed ? tol_band_guess : tol_band_keep, &nrep, rep.data(), piv.data()));
+            SX_TRY(sx_bandlu_factor_blocks_dev(lu, guessed ? tol_band_guess : tol_band_keep, static_cast<int>(P), P > 1 ? stride : m1, P > 1 ? RL : m1, P > 1 ? RL_last : m1, &nrep,
+                                                rep.data(), piv.data()));
             // a replaced column stands for the unit vector of the row that sat on its diagonal: a placeholder; the column
             // itself goes to the border
             std::vector<int32_t> rowof(static_cast<size_t>(m1));
@@ -1344,24 +1424,24 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                     ph_row[j] = rows_band[rowof[j]];
                 } else {
                     if (piv[j] != j) std::swap(rowof[j], rowof[piv[j]]);
-                    if (bvar[j] < 0) ph_row[j] = rows_band[j];
+                    if (bvar[j] == -1) ph_row[j] = rows_band[j];
                 }
             }
         }
-        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: band LU done at %.1f ms (kl=%d ku=%d, %lld columns set aside)\n", epochs, now() - t_begin, kl, ku, (long long)nrep);
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: band LU done at %.1f ms (kl=%d ku=%d, %lld blocks of %lld positions with separators of %lld, %lld columns set aside)\n", epochs, now() - t_begin, kl, ku, (long long)P, (long long)RL, (long long)Wsep, (long long)nrep);
         // ---------------------------------------------------------------- the border: as many columns as rows
         auto untrack = [&](int64_t v) { tracked.erase(std::remove(tracked.begin(), tracked.end(), static_cast<int32_t>(v)), tracked.end()); };
         std::vector<int64_t> bcol;
         for (int64_t v = 0; v < NV; ++v)
             if (is_basic[v] && !placed[v]) bcol.push_back(v);
         int64_t h = 0;
-        for (int64_t p = 0; p < m1; ++p) h += bvar[p] < 0;
+        for (int64_t p = 0; p < m1; ++p) h += bvar[p] == -1;
         {
             // too few columns for the border rows (or a border beyond the dense LU): placeholders become their row's own
             // logical, then the dense rows' logicals fill in; too many: the surplus leaves the basis (superbasic)
             std::vector<int32_t> gone;
             for (int64_t p = 0; p < m1 && (static_cast<int64_t>(bcol.size()) < ndr + h || ndr + h > MAX_NB); ++p) {
-                if (bvar[p] >= 0) continue;
+                if (bvar[p] != -1) continue;
                 const int64_t w = n + ph_row[p];
                 if (is_basic[w]) continue;
                 bvar[p] = w;
@@ -1397,9 +1477,25 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             }
         }
         const int64_t nb = ndr + h, mp = m1 + nb;
+        // the eta file of this epoch -- allocated now because its memory doubles as the work block of the Schur complement's
+        // assembly (a block of 24 GB allocated and freed for that alone cost 0.3 s at 1e5 rows and 1.2 s at 1e6: hipFree of a
+        // touched block).  Basis changes before the basis is factored afresh: a few times the columns that can move, within
+        // 16 GB; a fresh factorisation keeps every basic variable (bordered form), so the file need not be long
+        double *d_eta = nullptr;
+        int32_t *d_eta_r = nullptr;
+        int64_t EPOCH = 0;
+        {
+            size_t free_b = 0, total_b = 0;
+            SX_HIP(hipMemGetInfo(&free_b, &total_b));
+            const int64_t by_memory = std::max<int64_t>(64, static_cast<int64_t>(std::min(16.0e9, 0.4 * static_cast<double>(free_b)) / (8.0 * static_cast<double>(mp))) - 1);
+            EPOCH = std::min<int64_t>(std::min<int64_t>(20000, by_memory), 4 * static_cast<int64_t>(tracked.size() + static_cast<size_t>(nb) / 8) + 2048);
+            if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
+            SX_TRY(edev.get(static_cast<size_t>(mp) * (EPOCH + 1), &d_eta));
+            SX_TRY(edev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
+        }
         std::vector<int32_t> ph_pos;
         for (int64_t p = 0; p < m1; ++p)
-            if (bvar[p] < 0) ph_pos.push_back(static_cast<int32_t>(p));
+            if (bvar[p] == -1) ph_pos.push_back(static_cast<int32_t>(p));
         // ---- B21: the dense rows' entries in the band columns, one unit entry per placeholder row
         SxBorderOps ops;
         ops.ctx = ctx;
@@ -1456,26 +1552,41 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
         // ---- the Schur complement, a block of border columns at a time: S[:, j] = (a2 - B21 B11^-1 a1) of column j
         int64_t nrep2 = 0;
         if (nb > 0) {
+            {
+                size_t free_b = 0, total_b = 0;
+                SX_HIP(hipMemGetInfo(&free_b, &total_b));
+                ops.v_limit = static_cast<size_t>(std::min(4.0e9, 0.05 * static_cast<double>(free_b)) / 8.0);
+                if (getenv("SX_BAND_NO_V")) ops.v_failed = 1;
+            }
             SX_TRY(sx_denselu_create_dev(ctx, nb, &dl));
             double *Sa = nullptr;
             int64_t Sld = 0;
             SX_TRY(sx_denselu_matrix(dl, &Sa, &Sld));
-            const int64_t CH = std::max<int64_t>(16, std::min<int64_t>(std::min<int64_t>(nb, 1024), static_cast<int64_t>(2.0e9 / (8.0 * static_cast<double>(mp)))));
+            // blocks of up to 4,096 columns (in the memory of the still empty eta file: a sparse band solve is a chain of panel steps per
+            // group of 8 columns whatever the number of groups, 250 columns a launch kept 31 of 256 CUs busy), taken in the
+            // order of the VARIABLES -- neighbours in that order live in neighbouring rows, so the 8 columns of a group share
+            // their panels -- and written to the column of S the border's own order gives them
+            const int64_t CH = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 4096), EPOCH + 1));
             DevBufs sdev;
-            double *Wc = nullptr;
-            int32_t *d_bvars = nullptr;
-            SX_TRY(sdev.get(static_cast<size_t>(mp) * CH, &Wc));
+            double *Wc = d_eta; // (the eta file is empty until the simplex starts)
+            int32_t *d_bvars = nullptr, *d_dest = nullptr;
             SX_TRY(sdev.get(static_cast<size_t>(nb), &d_bvars));
-            std::vector<int32_t> bv32(bcol.begin(), bcol.end());
+            SX_TRY(sdev.get(static_cast<size_t>(nb), &d_dest));
+            std::vector<int32_t> order(static_cast<size_t>(nb)), bv32(static_cast<size_t>(nb));
+            std::iota(order.begin(), order.end(), 0);
+            std::sort(order.begin(), order.end(), [&](int32_t a, int32_t bb) { return bcol[a] < bcol[bb]; });
+            for (int64_t t = 0; t < nb; ++t) bv32[t] = static_cast<int32_t>(bcol[order[t]]);
             SX_TRY(up(s, d_bvars, bv32));
-            peak_bytes = std::max(peak_bytes, sizeof(double) * (static_cast<size_t>(mp) * CH + static_cast<size_t>(Sld) * nb));
+            SX_TRY(up(s, d_dest, order));
+            peak_bytes = std::max(peak_bytes, sizeof(double) * (static_cast<size_t>(mp) * (EPOCH + 1) + static_cast<size_t>(Sld) * nb));
             for (int64_t c0 = 0; c0 < nb; c0 += CH) {
                 const int64_t kc = std::min<int64_t>(CH, nb - c0);
                 SX_HIP(hipMemsetAsync(Wc, 0, sizeof(double) * static_cast<size_t>(mp) * kc, s));
                 hipLaunchKernelGGL(k_tb_scatter_cols, dim3(gridof(kc)), dim3(TB_WG), 0, s, kc, d_bvars + c0, n, A->csc_ptr, A->csc_idx, A->csc_val, d_eqidx, Wc, mp);
                 SX_TRY(ops.ftran(Wc, kc, true, true));
-                SX_HIP(hipMemcpy2DAsync(Sa + static_cast<size_t>(c0) * Sld, sizeof(double) * Sld, Wc + m1, sizeof(double) * mp, sizeof(double) * nb,
-                                        static_cast<size_t>(kc), hipMemcpyDeviceToDevice, s));
+                SX_TRY(ops.pack_v(Wc, kc, order.data() + c0)); // (the band parts B11^-1 B12 of these columns, by their windows)
+                hipLaunchKernelGGL(k_tb_copy_cols, dim3(static_cast<unsigned>(std::min<int64_t>(gridof(nb), 64)), static_cast<unsigned>(kc)), dim3(TB_WG), 0, s, nb, Wc + m1, mp,
+                                   d_dest + c0, Sa, Sld);
             }
             SX_HIP(hipStreamSynchronize(s));
             if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: Schur complement (%lld rows: %lld dense, %lld placeholders) assembled at %.1f ms\n", epochs, (long long)nb, (long long)ndr, (long long)h, now() - t_begin);
@@ -1511,6 +1622,7 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                 is_basic[w] = 1;
                 untrack(w);
             }
+            SX_TRY(ops.finish_v(rep2)); // (a column that left the basis: its V column is zero, like the unit vector's that replaced it)
             if (trace) {
                 std::vector<double> dg(static_cast<size_t>(nb));
                 SX_HIP(hipMemcpy2D(dg.data(), sizeof(double), Sa, sizeof(double) * (Sld + 1), sizeof(double), static_cast<size_t>(nb), hipMemcpyDeviceToHost));
@@ -1523,8 +1635,10 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                     c4 += a < 1e-4;
                     c6 += a < 1e-6;
                 }
-                fprintf(stderr, "[sx_crossover_band] epoch %d: Schur complement factored at %.1f ms (%lld columns set aside; smallest pivot %.2e, %lld / %lld / %lld below 1e-2 / 1e-4 / 1e-6)\n",
-                        epochs, now() - t_begin, (long long)nrep2, mn, (long long)c2, (long long)c4, (long long)c6);
+                fprintf(stderr, "[sx_crossover_band] epoch %d: Schur complement factored at %.1f ms (%lld columns set aside; smallest pivot %.2e, %lld / %lld / %lld below 1e-2 / 1e-4 / 1e-6); "
+                                "B11^-1 B12 %s: %.1f rows per border column, %.3f GB\n",
+                        epochs, now() - t_begin, (long long)nrep2, mn, (long long)c2, (long long)c4, (long long)c6, ops.v_ready ? "packed by windows" : "not kept (solve form)",
+                        static_cast<double>(ops.v_used) / static_cast<double>(nb), static_cast<double>(ops.v_used) * 8e-9);
             }
         }
         ops.dl = dl;
@@ -1554,8 +1668,12 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             rows_from_triplets(nb, ej, ep, ev, false, b12c);
             SX_TRY(rows_to_dev(b12r, static_cast<int64_t>(b12r.list.size()), true, ops.b12_rows));
             SX_TRY(rows_to_dev(b12c, nb, false, ops.b12_cols));
-            ops.work_cols = std::max<int64_t>(1, std::min<int64_t>(128, static_cast<int64_t>(1.0e9 / (8.0 * static_cast<double>(m1)))));
+            ops.work_cols = ops.v_ready ? 1 : std::max<int64_t>(1, std::min<int64_t>(128, static_cast<int64_t>(1.0e9 / (8.0 * static_cast<double>(m1)))));
             SX_TRY(edev.get(static_cast<size_t>(m1) * ops.work_cols, &ops.work));
+        }
+        if (trace) {
+            SX_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "[sx_crossover_band] epoch %d: border blocks in place at %.1f ms\n", epochs, now() - t_begin);
         }
         // ---- who is where
         std::vector<int64_t> head(static_cast<size_t>(mp), -1);
@@ -1586,12 +1704,12 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                 vstat[v] = 2;
                 varJ.push_back(v);
             }
+        std::sort(varJ.begin(), varJ.end()); // (neighbours in the order of the variables share the panels of a sparse band solve)
         int64_t nJ = static_cast<int64_t>(varJ.size());
         // ---------------------------------------------------------------- this epoch's blocks: positions, tableau, eta file
         const int nblk = static_cast<int>(gridof(mp));
-        double *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr, *d_vec = nullptr, *d_part = nullptr, *d_infpart = nullptr,
-               *d_eta = nullptr;
-        int32_t *d_head = nullptr, *d_blist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr, *d_eta_r = nullptr;
+        double *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr, *d_vec = nullptr, *d_part = nullptr, *d_infpart = nullptr;
+        int32_t *d_head = nullptr, *d_blist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr;
         TbPart *d_rpart = nullptr;
         SX_TRY(edev.get(static_cast<size_t>(mp), &d_xB));
         SX_TRY(edev.get(static_cast<size_t>(mp), &d_lB));
@@ -1606,27 +1724,20 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
         SX_TRY(edev.get(static_cast<size_t>(nblk), &d_infoff));
         SX_TRY(edev.get(static_cast<size_t>(TB_INFLIST), &d_inflist));
         SX_TRY(edev.get(static_cast<size_t>(nblk), &d_rpart));
-        // basis changes before the basis is factored afresh (bounds the eta file and the drift of the tableau); a fresh
-        // factorisation keeps every basic variable (bordered form), so the file need not be long
-        int64_t EPOCH = std::min<int64_t>(20000, std::max<int64_t>(2 * nJ + 512, static_cast<int64_t>(16.0e9 / (8.0 * static_cast<double>(mp)))));
         TbSlots sl;
         {
             size_t free_b = 0, total_b = 0;
             SX_HIP(hipMemGetInfo(&free_b, &total_b));
-            int64_t cap0 = nJ + std::max<int64_t>(256, nJ / 4);
+            int64_t cap0 = nJ + std::max<int64_t>(512, nJ / 2); // (growing it later is an allocation, a copy and a free of GBs)
             if (static_cast<double>(TbSlots::bytes_for(mp, cap0)) > 0.6 * static_cast<double>(free_b)) cap0 = nJ + 16;
             if (static_cast<double>(TbSlots::bytes_for(mp, cap0)) > 0.8 * static_cast<double>(free_b)) {
                 sx_set_error("the tableau of %lld tracked columns over %lld positions does not fit the free device memory", (long long)cap0, (long long)mp);
                 return SX_ERR_NOMEM;
             }
             SX_TRY(sl.reserve(s, mp, cap0, 0));
-            SX_HIP(hipMemGetInfo(&free_b, &total_b));
-            EPOCH = std::min<int64_t>(EPOCH, std::max<int64_t>(64, static_cast<int64_t>(0.5 * static_cast<double>(free_b) / (8.0 * static_cast<double>(mp))) - 1));
-            if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
-            SX_TRY(edev.get(static_cast<size_t>(mp) * (EPOCH + 1), &d_eta));
-            SX_TRY(edev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
             peak_bytes = std::max(peak_bytes, TbSlots::bytes_for(mp, cap0) + sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1));
         }
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: tableau and position blocks allocated at %.1f ms\n", epochs, now() - t_begin);
         // ---------------------------------------------------------------- values: non-basic and tracked columns, right-hand side
         // logical of row i: s_i = b_i - (A x)_i for the tracked ones (their current value), 0 for the non-basic ones
         SX_TRY(up(s, d_tmpn, hx));
@@ -1697,7 +1808,31 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             SX_TRY(up(s, d_xB, rp));
             SX_HIP(hipStreamSynchronize(s));
         }
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: right-hand side and basic variables' arrays at %.1f ms\n", epochs, now() - t_begin);
         SX_TRY(ftran_cols(d_xB, 1, 0, false));
+        if (vbasis_in && epochs == 1 && !strict_tried) {
+            // a GIVEN basis is kept as it is (tolerances of a basis the simplex has reached) -- unless its basic solution says it
+            // is no basis to start from: members that are all but dependent put it far outside the bounds, and phase 1 would
+            // pay for each of them pivot by pivot (15 wrong members of 1,200: 6,537 iterations against 402 from the point alone).
+            // Then the same set is factored once more with the tolerances of a guess
+            std::vector<double> t;
+            SX_TRY(down(s, t, d_xB, static_cast<size_t>(mp)));
+            SX_HIP(hipStreamSynchronize(s));
+            double worst = 0.0;
+            int64_t ninf = 0;
+            for (int64_t p = 0; p < mp; ++p) {
+                if (head[p] < 0) continue;
+                const double vi = std::max(var_lo(head[p]) - t[p], t[p] - var_up(head[p]));
+                if (vi > feas_tol) ++ninf;
+                worst = std::max(worst, vi);
+            }
+            strict_tried = true;
+            if (worst > 1.0 || ninf > std::max<int64_t>(16, m / 50)) {
+                if (trace) fprintf(stderr, "[sx_crossover_band] the given basis puts %lld variables outside their bounds (worst %.3e): factored again with the tolerances of a guess\n", (long long)ninf, worst);
+                strict_next = true;
+                continue;
+            }
+        }
         if (trace) { // how far the basic solution is from the point handed over (conditioning of the guessed basis)
             std::vector<double> t;
             SX_TRY(down(s, t, d_xB, static_cast<size_t>(mp)));
@@ -1892,12 +2027,13 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             std::sort(viol.begin(), viol.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &bb) { return a.first > bb.first || (a.first == bb.first && a.second < bb.second); });
             const int64_t take = std::min<int64_t>(static_cast<int64_t>(viol.size()), 2048);
             if (nJ + take > sl.cap) { // (nothing is pending here: the run stopped, its batch was folded)
-                const int rc_ = sl.reserve(s, mp, nJ + take + std::max<int64_t>(256, nJ / 2), nJ);
+                const int rc_ = sl.reserve(s, mp, nJ + take + std::max<int64_t>(512, nJ / 2), nJ);
                 if (rc_ != SX_OK) return rc_;
                 peak_bytes = std::max(peak_bytes, 2 * TbSlots::bytes_for(mp, nJ) + sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1));
             }
             std::vector<int32_t> add(static_cast<size_t>(take));
             for (int64_t t = 0; t < take; ++t) add[t] = viol[t].second;
+            std::sort(add.begin(), add.end());
             for (int32_t v : add)
                 if (v >= n) xlog[v - n] = 0.0;
             SX_TRY(load_slots(nJ, add));
@@ -1926,7 +2062,7 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
         std::fill(vstat.begin(), vstat.end(), 0);
         tracked.clear();
         viol_max = 0.0;
-        prev_pos.assign(static_cast<size_t>(m1), -1);
+        prev_pos.assign(static_cast<size_t>(m1_all), -1);
         for (int64_t p = 0; p < mp; ++p) {
             const int64_t v = hh[p];
             if (v < 0) continue;
@@ -1934,7 +2070,7 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             vstat[v] = 1;
             viol_max = std::max(viol_max, std::max(var_lo(v) - hxb[p], hxb[p] - var_up(v)));
             if (v < n) hx[v] = hxb[p];
-            if (p < m1 && v == head[p]) prev_pos[p] = v;
+            if (p < m1 && v == head[p] && old_of_new[p] >= 0) prev_pos[old_of_new[p]] = v;
         }
         for (int64_t t = 0; t < nJ; ++t) {
             const int64_t v = hvarJ[t];
@@ -1959,18 +2095,51 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             SX_TRY(sx_score_rows_dev(ctx, A, d_tmpn, b, nullptr, 0.0, d_tmpm, nullptr));
             SX_TRY(down(s, hslack, d_tmpm, static_cast<size_t>(m)));
             SX_HIP(hipStreamSynchronize(s));
-            resid_max = 0.0;
-            double rc_basic = 0.0;
-            for (int64_t i = 0; i < m; ++i) {
-                const double sc = 1.0 + std::fabs(hb[i]);
-                const double r = hlt[i] ? std::max(-hslack[i], 0.0) : std::fabs(hslack[i]);
-                resid_max = std::max(resid_max, r / sc);
+            auto row_residual = [&]() {
+                double worst = 0.0;
+                for (int64_t i = 0; i < m; ++i) {
+                    const double sc = 1.0 + std::fabs(hb[i]);
+                    const double r = hlt[i] ? std::max(-hslack[i], 0.0) : std::fabs(hslack[i]);
+                    worst = std::max(worst, r / sc);
+                }
+                return worst;
+            };
+            resid_max = row_residual();
+            if (resid_max > 1e-11) {
+                // one step of iterative refinement with the factors at hand: B delta = b - A x - s (s: the logicals'
+                // values), x_B += delta -- what thousands of updates x_B -= theta alpha left behind goes at once
+                std::vector<double> slog(static_cast<size_t>(m), 0.0), rr(static_cast<size_t>(mp), 0.0), delta;
+                for (int64_t p = 0; p < mp; ++p)
+                    if (hh[p] >= n) slog[hh[p] - n] = hxb[p];
+                for (int64_t t = 0; t < nJ; ++t)
+                    if (hvarJ[t] >= n) slog[hvarJ[t] - n] = hxJ[t];
+                for (int64_t i = 0; i < m; ++i) rr[eqidx[i]] = hslack[i] - slog[i];
+                SX_TRY(up(s, d_vec, rr));
+                SX_TRY(ftran_cols(d_vec, 1, hst.n_eta, false));
+                SX_TRY(down(s, delta, d_vec, static_cast<size_t>(mp)));
+                SX_HIP(hipStreamSynchronize(s));
+                viol_max = 0.0;
+                for (int64_t p = 0; p < mp; ++p) {
+                    const int64_t v = hh[p];
+                    if (v < 0) continue;
+                    hxb[p] += delta[p];
+                    viol_max = std::max(viol_max, std::max(var_lo(v) - hxb[p], hxb[p] - var_up(v)));
+                    if (v < n) hx[v] = hxb[p];
+                }
+                SX_TRY(up(s, d_tmpn, hx));
+                SX_TRY(sx_score_rows_dev(ctx, A, d_tmpn, b, nullptr, 0.0, d_tmpm, nullptr));
+                SX_TRY(down(s, hslack, d_tmpm, static_cast<size_t>(m)));
+                SX_HIP(hipStreamSynchronize(s));
+                const double before = resid_max;
+                resid_max = row_residual();
+                if (trace) fprintf(stderr, "[sx_crossover_band] refinement of x_B: row residual %.2e -> %.2e (relative), bound violation %.2e\n", before, resid_max, viol_max);
             }
+            double rc_basic = 0.0;
             if (static_cast<int64_t>(hrc.size()) == n)
                 for (int64_t j = 0; j < n; ++j)
                     if (vstat[j] == 1) rc_basic = std::max(rc_basic, std::fabs(hrc[j]) / (1.0 + std::fabs(hc[j])));
             if (trace) fprintf(stderr, "[sx_crossover_band] check of the vertex: row residual %.2e (relative), reduced costs of basic columns %.2e\n", resid_max, rc_basic);
-            if (resid_max > 10.0 * feas_tol || rc_basic > 10.0 * opt_tol) {
+            if (resid_max > 10.0 * feas_tol || rc_basic > 10.0 * opt_tol || viol_max > 10.0 * feas_tol) {
                 if (check_epochs < 2 && tot_iters < max_iter) {
                     ++check_epochs;
                     continue;
@@ -1979,6 +2148,7 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             }
         }
         break;
+        } // (this epoch's geometry)
     }
     // ------------------------------------------------------------------ outputs
     std::vector<int8_t> vb(static_cast<size_t>(n)), cb(static_cast<size_t>(m), -1);

@@ -349,6 +349,14 @@ class BandLU:
         _l.check(self.ctx._lib.sx_bandlu_factor_dev(self.handle, float(pivot_tol), C.byref(cnt), rep.ctypes.data, piv.ctypes.data))
         return rep, piv
 
+    def factor_blocks(self, nblocks: int, stride: int, real_len: int, real_len_last: int, pivot_tol: float = 1e-11):
+        """factor() for a block-diagonal matrix with identity padding between its blocks: the blocks side by side."""
+        cnt = C.c_int64(0)
+        rep, piv = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        _l.check(self.ctx._lib.sx_bandlu_factor_blocks_dev(self.handle, float(pivot_tol), int(nblocks), int(stride), int(real_len),
+                                                           int(real_len_last), C.byref(cnt), rep.ctypes.data, piv.ctypes.data))
+        return rep, piv
+
     def solve(self, X: "DeviceArray", nrhs: int = 1, ldx: Optional[int] = None, trans: bool = False) -> None:
         _l.check(self.ctx._lib.sx_bandlu_solve_dev(self.handle, int(bool(trans)), int(nrhs), X.ptr, int(ldx or self.n)))
 

@@ -199,3 +199,46 @@ def test_partitioned_sweeps_agree_with_the_sequential_ones(ctx, monkeypatch, swa
         assert np.abs((M.T if trans else M) @ got - B).max() <= 1e-11 * (1 + scale), (nrhs, trans)
     seq.free()
     par.free()
+
+
+@pytest.mark.parametrize("nblocks,real,last,kl,ku", [(4, 640, 500, 40, 25), (7, 1280, 1290, 117, 113), (3, 96, 33, 5, 3)])
+def test_blocks_factored_side_by_side_match_lapack(ctx, nblocks, real, last, kl, ku):
+    """factor_blocks: a block-diagonal band matrix with identity padding of kl + ku + 32 positions (rounded up to whole
+    panels) between its blocks, the blocks' panels factored side by side -- pivoting has to swap rows inside every block;
+    the solves (both orientations, one and many right-hand sides) against LAPACK, and the same factors as the sequential
+    factorisation of the same matrix bit for bit."""
+    from scipy.sparse.linalg import splu
+    from smart_crossover.hip.device import BandLU
+    pad = (kl + ku + 32 + 31) // 32 * 32
+    stride = real + pad
+    n = (nblocks - 1) * stride + last
+    blocks, rows, cols, vals = [], [], [], []
+    for b in range(nblocks):
+        nb_ = real if b < nblocks - 1 else last
+        Ab = sp.coo_matrix(band_matrix(nb_, min(kl, nb_ - 1), min(ku, nb_ - 1), 100 + b, density=1.0))   # (a full band: no block is singular)
+        rows.append(Ab.row + b * stride); cols.append(Ab.col + b * stride); vals.append(Ab.data)
+        if b < nblocks - 1:
+            idx = np.arange(b * stride + real, (b + 1) * stride)
+            rows.append(idx); cols.append(idx); vals.append(np.ones(idx.size))
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    C = sp.coo_matrix(A)
+    put = lambda v, t: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    lu = BandLU(ctx, n, kl, ku, put(C.row, np.int32), put(C.col, np.int32), put(C.data, np.float64))
+    rep, piv = lu.factor_blocks(nblocks, stride, real, last)
+    assert rep.sum() == 0 and np.any(piv != np.arange(n))
+    seq = BandLU(ctx, n, kl, ku, put(C.row, np.int32), put(C.col, np.int32), put(C.data, np.float64))
+    rep2, piv2 = seq.factor()
+    assert np.array_equal(piv, piv2) and np.array_equal(rep, rep2)
+    ref = splu(sp.csc_matrix(A))
+    rng = np.random.default_rng(3)
+    for nrhs in (1, 19):
+        B = rng.standard_normal((n, nrhs))
+        for trans in (False, True):
+            want = ref.solve(B, trans="T" if trans else "N")
+            for h in (lu, seq):
+                X = ctx.to_device(np.asfortranarray(B).ravel(order="F"))
+                h.solve(X, nrhs, n, trans)
+                got = X.download().reshape((n, nrhs), order="F")
+                assert np.abs(got - want).max() <= 1e-9 * (1 + np.abs(want).max())
+    lu.free()
+    seq.free()

@@ -136,13 +136,15 @@ def small_band_lp(m=400, n=1600, seed=11):
     return inst
 
 
-def direct(ctx, A, b, c, l, u, lt, x_start):
+def direct(ctx, A, b, c, l, u, lt, x_start, vbasis_in=None, cbasis_in=None):
     m, n = A.shape
     dA = ctx.matrix(A)
     put = lambda v, t=np.float64: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
     d_x, d_y = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
     d_vb, d_cb = ctx.empty(n, np.int8), ctx.empty(m, np.int8)
-    res = ctx.crossover_band(dA, put(b), put(c), put(l), put(u), put(lt, np.uint8), put(x_start), 0, 1e-7, 1e-7, d_x, d_y, d_vb, d_cb)
+    res = ctx.crossover_band(dA, put(b), put(c), put(l), put(u), put(lt, np.uint8), put(x_start), 0, 1e-7, 1e-7, d_x, d_y, d_vb, d_cb,
+                             vbasis_in=None if vbasis_in is None else put(vbasis_in, np.int8),
+                             cbasis_in=None if cbasis_in is None else put(cbasis_in, np.int8))
     out = (res, d_x.download(), d_y.download(), d_vb.download().astype(int), d_cb.download().astype(int))
     dA.free()
     return out
@@ -255,3 +257,150 @@ def test_another_cost_brings_columns_in_by_pricing(ctx, seed, scale):
     rc = c - inst.A.T @ y
     assert np.all(rc[vb == -1] >= -1e-6) and np.all(rc[vb == -2] <= 1e-6) and np.abs(rc[vb == 0]).max() < 1e-6
     assert int((vb == 0).sum() + (cb == 0).sum()) == inst.A.shape[0]
+
+
+def vertex_checks(A, b, c, l, u, lt, x, y, vb, cb, tol=1e-6):
+    s_p = b - A @ x
+    assert np.abs(s_p[~lt]).max(initial=0.0) <= tol and s_p[lt].min(initial=0.0) >= -tol
+    assert np.all(x >= l - 1e-9) and np.all(x <= u + 1e-9)
+    rc = c - A.T @ y
+    assert np.all(rc[vb == -1] >= -tol) and np.all(rc[vb == -2] <= tol) and np.abs(rc[vb == 0]).max(initial=0.0) <= tol
+    assert int((vb == 0).sum() + (cb == 0).sum()) == A.shape[0] and not np.any(vb == -3)
+
+
+def test_a_given_optimal_basis_is_factored_as_it_is_and_needs_no_pivot(ctx):
+    """sx_crossover_band_basis_dev, the warm-started simplex of the reference's last step (lp_methods/algorithms.py:69-74)
+    on the bordered factorisation: the optimal basis of a first run handed back -> every member is in the factors (none is
+    re-guessed), 0 iterations, the same vertex; then the same basis with a few members swapped for wrong ones and with
+    members missing (completed by logicals) -> a few pivots back to the same optimum."""
+    inst = small_band_lp(1200, 6000, seed=21)
+    lt = inst.sense == "<"
+    first = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, inst.x)
+    assert int(first[0].status) == 0 and int(first[0].iters) > 0
+    _, x0, y0, vb0, cb0 = first
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, x0, vb0, cb0)
+    assert int(res.status) == 0 and int(res.iters) == 0 and int(res.warm_start_used) == 1
+    assert np.array_equal(vb, vb0) and np.array_equal(cb, cb0)
+    np.testing.assert_allclose(x, x0, rtol=1e-9, atol=1e-10)
+    obj0 = float(inst.c @ x0)
+    rng = np.random.default_rng(4)
+    # (a) members swapped: 15 basic columns declared non-basic at their lower bound, 15 non-basic ones declared basic
+    vb1 = vb0.copy()
+    out_ = rng.choice(np.flatnonzero(vb0 == 0), 15, replace=False)
+    in_ = rng.choice(np.flatnonzero(vb0 == -1), 15, replace=False)
+    vb1[out_], vb1[in_] = -1, 0
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, x0, vb1, cb0)
+    assert int(res.status) == 0 and 0 < int(res.iters) <= int(first[0].iters)      # (no worse than from the point alone)
+    assert float(inst.c @ x) == pytest.approx(obj0, rel=1e-9, abs=1e-9)
+    vertex_checks(inst.A, inst.b, inst.c, inst.l, inst.u, lt, x, y, vb, cb)
+    # (b) members missing: 25 basic columns dropped and nothing put in their place
+    vb2 = vb0.copy()
+    vb2[rng.choice(np.flatnonzero(vb0 == 0), 25, replace=False)] = -1
+    res, x, y, vb, cb = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, x0, vb2, cb0)
+    assert int(res.status) == 0
+    assert float(inst.c @ x) == pytest.approx(obj0, rel=1e-9, abs=1e-9)
+    vertex_checks(inst.A, inst.b, inst.c, inst.l, inst.u, lt, x, y, vb, cb)
+
+
+def test_final_warm_simplex_of_run_perturb_algorithm_takes_the_sparse_path(ctx, monkeypatch):
+    """run_perturb_algorithm forced down its last branch (lp_methods/algorithms.py:69-74: the gap test answers None) on
+    netlib_lp(20000, 200000): the perturbed re-solve AND the warm-started primal simplex on the ORIGINAL 20,000 x 200,000 LP
+    run on the device, the latter from the recovered basis through the sparse path (a dense inverse of the original LP
+    would be 3.2 GB installed by 20,000 crash pivots).  The interior point is the instance's own strictly complementary
+    pair (HiGHS' barrier does not finish on this family, profiles/r03): the optimal value is c^T x of that pair."""
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    from smart_crossover.output import Output
+    from smart_crossover.solver_caller import hip as hipmod
+    inst = workloads.netlib_lp(20000, 200000, seed=3)
+    lp = GeneralLP(inst.A, inst.b, inst.c, inst.l, inst.u, inst.sense)
+    real_solve = alg.solve_lp
+    seen = []
+
+    def fake_solve(lp_, solver="GRB", method="default", settings=None, **kw):
+        if method == "barrier" and settings is not None and settings.crossover == "off":
+            return Output(x=inst.x, y=inst.y, obj_val=float(inst.c @ inst.x), status="OPTIMAL")
+        out = real_solve(lp_, solver, method, settings=settings, **kw)
+        seen.append((method, lp_.A.shape, "warm_start_basis" in kw and kw["warm_start_basis"] is not None, out.iter_count))
+        return out
+
+    band_calls = []
+    real_band = hipmod.HipCaller._band
+
+    def spy_band(self, *a, **k):
+        r = real_band(self, *a, **k)
+        band_calls.append((self._A.shape, None if r is None else int(r.status), None if r is None else int(r.iters)))
+        return r
+
+    monkeypatch.setattr(alg, "solve_lp", fake_solve)
+    monkeypatch.setattr(alg, "check_feasibility_problem", lambda lp_: False)
+    monkeypatch.setattr(alg, "check_perturb_output_precision", lambda *a, **k: None)
+    monkeypatch.setattr(hipmod.HipCaller, "_band", spy_band)
+    monkeypatch.setenv("SX_LP_CROSSOVER", "band")
+    with redirect_stdout(io.StringIO()):
+        out = alg.run_perturb_algorithm(lp, "HIP")
+    assert out.status == "OPTIMAL"
+    assert [c[0] for c in seen] == ["barrier", "primal_simplex"] and seen[1][1] == (20000, 200000) and seen[1][2]
+    assert len(band_calls) == 2 and band_calls[1][0] == (20000, 200000) and band_calls[1][1] == 0     # both re-solves on the sparse path
+    assert band_calls[1][2] <= 200          # the recovered basis is (next to) optimal for the original LP: a few pivots at most
+    lt = inst.sense == "<"
+    vertex_checks(inst.A, inst.b, inst.c, inst.l, inst.u, lt, out.x, out.y, out.basis.vbasis, out.basis.cbasis)
+    assert float(inst.c @ out.x) == pytest.approx(float(inst.c @ inst.x), rel=1e-7, abs=1e-7)
+
+
+def test_warm_start_at_headline_size_returns_without_a_pivot(ctx, monkeypatch):
+    """A 1e5-row warm start from the optimal basis (the perturbed sub-problem of the 1e6-variable LP): factored as given,
+    0 iterations."""
+    from smart_crossover.solver_caller import solving
+    from smart_crossover.solver_caller.caller import SolverSettings
+    inst = workloads.netlib_lp()
+    lp, mgr = perturbed_sub_problem(inst)
+    caller, out = resolve(mgr, inst, monkeypatch, "auto")
+    assert caller.solved_by == "crossover_band" and out.status == "OPTIMAL"
+    with redirect_stdout(io.StringIO()):
+        again = solving.solve_lp(mgr.lp_sub, "HIP", "primal_simplex", SolverSettings(presolve="on", log_console=0),
+                                 warm_start_basis=out.basis, warm_start_solution=(out.x, out.y))
+    assert again.status == "OPTIMAL" and int(again.iter_count) == 0
+    np.testing.assert_allclose(again.x, out.x, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(again.basis.vbasis, out.basis.vbasis) and np.array_equal(again.basis.cbasis, out.basis.cbasis)
+
+
+def test_infeasible_perturbation_widens_the_face_and_retries(ctx, monkeypatch):
+    """run_perturb_algorithm's retry loop (lp_methods/algorithms.py:45-61) through K16p + K16s at 30,000 rows: the first
+    re-solve is INFEASIBLE -- at gamma = 1e-3 the indicator test fixes EVERY column of one equality row at a bound (their
+    dual slacks are made large: c_k += 2e3 (x_k - l_k) in the LP handed over), the row is left empty with a right-hand side
+    that is not zero --, gamma is multiplied by 1e-5 (those columns stay free: 1e-8 * 2e3 < 1) and the second re-solve
+    succeeds."""
+    from smart_crossover.formats import GeneralLP
+    from smart_crossover.lp_methods import algorithms as alg
+    from smart_crossover.output import Output
+    inst = workloads.netlib_lp(30000, 300000, seed=9)
+    lt = inst.sense == "<"
+    A = inst.A.tocsr()
+    i = int(np.flatnonzero(~lt)[1000])
+    cols = A[i].indices
+    interior = cols[(inst.x[cols] - inst.l[cols] > 1e-6) & (inst.u[cols] - inst.x[cols] > 1e-6)]
+    assert interior.size >= 1
+    lp = GeneralLP(inst.A, inst.b, inst.c.copy(), inst.l, inst.u, inst.sense)
+    lp.c[interior] += 2e3 * (inst.x[interior] - inst.l[interior])
+    real_solve = alg.solve_lp
+    statuses = []
+
+    def fake_solve(lp_, solver="GRB", method="default", settings=None, **kw):
+        if method == "barrier" and settings is not None and settings.crossover == "off":
+            return Output(x=inst.x, y=inst.y, obj_val=float(lp.c @ inst.x), status="OPTIMAL")
+        out = real_solve(lp_, solver, method, settings=settings, **kw)
+        statuses.append((method, lp_.A.shape, out.status))
+        return out
+
+    monkeypatch.setattr(alg, "solve_lp", fake_solve)
+    monkeypatch.setattr(alg, "check_feasibility_problem", lambda lp_: False)
+    monkeypatch.setattr(alg, "check_perturb_output_precision", lambda *a, **k: True)   # (the changed costs are not the point here)
+    monkeypatch.setenv("SX_LP_CROSSOVER", "band")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        out = alg.run_perturb_algorithm(lp, "HIP")
+    assert [(st[0], st[2]) for st in statuses] == [("barrier", "INFEASIBLE"), ("barrier", "OPTIMAL")]
+    assert statuses[1][1][1] > statuses[0][1][1]          # the wider face keeps more columns
+    assert "Increasing the optimal face and try again" in buf.getvalue()
+    assert out.status == "OPTIMAL"
