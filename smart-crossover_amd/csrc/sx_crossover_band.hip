@@ -30,6 +30,7 @@
 #include <cstring>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 namespace {
 
@@ -882,10 +883,47 @@ inline unsigned gridof(int64_t n) { return static_cast<unsigned>(n > 0 ? (n + TB
 inline unsigned gridcap(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(gridof(n), 1 << 20)); } // for grid-stride kernels
 
 
+// The two big blocks of an epoch -- eta file and tableau, tens of GB at 1e6 rows -- out of ONE block that a helper thread
+// allocates while the host matches columns to rows: hipMalloc of a block that size takes as long as the matching itself
+// (0.24 s for 12 GB + ~0.3 s for 16 GB at config-5 size, measured between two trace lines with nothing else in them)
+struct BigArena {
+    void *base = nullptr;
+    size_t bytes = 0, used = 0;
+    int device = 0;
+    std::thread th;
+    void start(int dev, size_t want) {
+        device = dev;
+        bytes = want;
+        th = std::thread([this]() {
+            if (hipSetDevice(device) != hipSuccess || hipMalloc(&base, bytes) != hipSuccess) {
+                base = nullptr;
+                (void)hipGetLastError();
+            }
+        });
+    }
+    void join() {
+        if (th.joinable()) th.join();
+    }
+    void *take(size_t n) { // nullptr: no room (the caller allocates for itself)
+        join();
+        n = (n + 255) & ~static_cast<size_t>(255);
+        if (!base || used + n > bytes) return nullptr;
+        void *q = static_cast<char *>(base) + used;
+        used += n;
+        return q;
+    }
+    void reset() { used = 0; }
+    ~BigArena() {
+        join();
+        (void)hipFree(base);
+    }
+};
+
 // per-slot arrays of the tableau (one slot per tracked column) and the tableau itself; grown when pricing brings in more
 // columns than there is room for (the explicit tableau of round 3 was sized once, at 90 % of the free memory)
 struct TbSlots {
     int64_t mp = 0, cap = 0;
+    bool T_own = true; // false: T is a piece of the call's arena
     double *T = nullptr, *xJ = nullptr, *lJ = nullptr, *uJ = nullptr, *cJ = nullptr, *dJ = nullptr, *d1 = nullptr, *rowbuf = nullptr,
            *vbuf = nullptr, *ebG = nullptr, *ebS = nullptr;
     int32_t *varJ = nullptr, *statJ = nullptr, *s0 = nullptr, *sbase = nullptr, *elist = nullptr;
@@ -893,12 +931,12 @@ struct TbSlots {
     TbSlots(const TbSlots &) = delete;
     TbSlots &operator=(const TbSlots &) = delete;
     ~TbSlots() {
-        for (void *q : {(void *)T, (void *)xJ, (void *)lJ, (void *)uJ, (void *)cJ, (void *)dJ, (void *)d1, (void *)rowbuf, (void *)vbuf, (void *)ebG,
+        for (void *q : {(void *)(T_own ? T : nullptr), (void *)xJ, (void *)lJ, (void *)uJ, (void *)cJ, (void *)dJ, (void *)d1, (void *)rowbuf, (void *)vbuf, (void *)ebG,
                         (void *)ebS, (void *)varJ, (void *)statJ, (void *)s0, (void *)sbase, (void *)elist})
             (void)hipFree(q);
     }
     void swap_with(TbSlots &o) {
-        std::swap(mp, o.mp); std::swap(cap, o.cap); std::swap(T, o.T); std::swap(xJ, o.xJ); std::swap(lJ, o.lJ); std::swap(uJ, o.uJ);
+        std::swap(mp, o.mp); std::swap(cap, o.cap); std::swap(T_own, o.T_own); std::swap(T, o.T); std::swap(xJ, o.xJ); std::swap(lJ, o.lJ); std::swap(uJ, o.uJ);
         std::swap(cJ, o.cJ); std::swap(dJ, o.dJ); std::swap(d1, o.d1); std::swap(rowbuf, o.rowbuf); std::swap(vbuf, o.vbuf); std::swap(ebG, o.ebG);
         std::swap(ebS, o.ebS); std::swap(varJ, o.varJ); std::swap(statJ, o.statJ); std::swap(s0, o.s0); std::swap(sbase, o.sbase); std::swap(elist, o.elist);
     }
@@ -906,19 +944,23 @@ struct TbSlots {
         return sizeof(double) * (static_cast<size_t>(mp_) * cap_ + static_cast<size_t>(7 + TB_K + 2 * TB_EB) * cap_) + sizeof(int32_t) * 5 * static_cast<size_t>(cap_);
     }
     // capacity newcap, the first `keep` slots (and tableau columns) carried over
-    int reserve(hipStream_t s, int64_t mp_, int64_t newcap, int64_t keep) {
+    int reserve(hipStream_t s, int64_t mp_, int64_t newcap, int64_t keep, BigArena *arena = nullptr) {
         if (newcap <= cap && mp_ == mp) return SX_OK;
         TbSlots nw;
         nw.mp = mp_;
         nw.cap = newcap;
         const size_t c = static_cast<size_t>(newcap);
+        if (arena) {
+            nw.T = static_cast<double *>(arena->take(sizeof(double) * static_cast<size_t>(mp_) * c));
+            nw.T_own = nw.T == nullptr;
+        }
 #define TB_GET(field, count)                                                                                                       \
     if (hipMalloc(reinterpret_cast<void **>(&nw.field), sizeof(*nw.field) * (count)) != hipSuccess) {                               \
         sx_set_error("hipMalloc of %zu bytes failed in the sparse crossover (tableau of %lld columns over %lld positions)",        \
                      sizeof(*nw.field) * (count), (long long)newcap, (long long)mp_);                                              \
         return SX_ERR_NOMEM;                                                                                                       \
     }
-        TB_GET(T, static_cast<size_t>(mp_) * c)
+        if (!nw.T) TB_GET(T, static_cast<size_t>(mp_) * c)
         TB_GET(xJ, c) TB_GET(lJ, c) TB_GET(uJ, c) TB_GET(cJ, c) TB_GET(dJ, c) TB_GET(d1, c) TB_GET(rowbuf, c)
         TB_GET(vbuf, static_cast<size_t>(TB_K) * c) TB_GET(ebG, static_cast<size_t>(TB_EB) * c) TB_GET(ebS, static_cast<size_t>(TB_EB) * c)
         TB_GET(varJ, c) TB_GET(statJ, c) TB_GET(s0, c) TB_GET(sbase, c) TB_GET(elist, c)
@@ -1186,6 +1228,18 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             else tracked.push_back(static_cast<int32_t>(cand[k]));
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] m=%lld n=%lld: %zu interior candidates, band rows %lld, dense rows %lld\n", (long long)m, (long long)n, cand.size(), (long long)m1, (long long)ndr);
+    }
+    // ------------------------------------------------------------------ the big blocks, allocated beside the matching
+    BigArena arena;
+    {
+        size_t free_b = 0, total_b = 0;
+        SX_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double mp_est = static_cast<double>(m) + static_cast<double>(ndr) + 33.0 * 400.0 + 2048.0;
+        const double nb_est = static_cast<double>(ndr) + 32.0 * 240.0 + 1024.0;
+        const double track_est = static_cast<double>(tracked.size()) + nb_est / 8.0;
+        const double epoch_est = std::min(std::min(20000.0, std::min(16.0e9, 0.4 * static_cast<double>(free_b)) / (8.0 * mp_est)), 4.0 * track_est + 2048.0);
+        const double want = 8.0 * mp_est * (epoch_est + 2.0 + 1.6 * track_est + 600.0);
+        if (want > 2.0e9 && want < 0.6 * static_cast<double>(free_b) && !getenv("SX_BAND_NO_ARENA")) arena.start(ctx->device, static_cast<size_t>(want));
     }
     // ------------------------------------------------------------------ small per-call blocks
     TbState *d_st = nullptr;
@@ -1490,7 +1544,9 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             const int64_t by_memory = std::max<int64_t>(64, static_cast<int64_t>(std::min(16.0e9, 0.4 * static_cast<double>(free_b)) / (8.0 * static_cast<double>(mp))) - 1);
             EPOCH = std::min<int64_t>(std::min<int64_t>(20000, by_memory), 4 * static_cast<int64_t>(tracked.size() + static_cast<size_t>(nb) / 8) + 2048);
             if (const char *e = getenv("SX_BAND_EPOCH")) EPOCH = std::max<int64_t>(16, atoll(e));
-            SX_TRY(edev.get(static_cast<size_t>(mp) * (EPOCH + 1), &d_eta));
+            arena.reset(); // (what the last epoch held there is dead)
+            d_eta = static_cast<double *>(arena.take(sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1)));
+            if (!d_eta) SX_TRY(edev.get(static_cast<size_t>(mp) * (EPOCH + 1), &d_eta));
             SX_TRY(edev.get(static_cast<size_t>(EPOCH) + 2, &d_eta_r));
         }
         std::vector<int32_t> ph_pos;
@@ -1734,7 +1790,7 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                 sx_set_error("the tableau of %lld tracked columns over %lld positions does not fit the free device memory", (long long)cap0, (long long)mp);
                 return SX_ERR_NOMEM;
             }
-            SX_TRY(sl.reserve(s, mp, cap0, 0));
+            SX_TRY(sl.reserve(s, mp, cap0, 0, &arena));
             peak_bytes = std::max(peak_bytes, TbSlots::bytes_for(mp, cap0) + sizeof(double) * static_cast<size_t>(mp) * (EPOCH + 1));
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: tableau and position blocks allocated at %.1f ms\n", epochs, now() - t_begin);

@@ -404,3 +404,81 @@ def test_infeasible_perturbation_widens_the_face_and_retries(ctx, monkeypatch):
     assert statuses[1][1][1] > statuses[0][1][1]          # the wider face keeps more columns
     assert "Increasing the optimal face and try again" in buf.getvalue()
     assert out.status == "OPTIMAL"
+
+
+def wide_band_lp(m=4000, per_row=2, below=1000, above=960, seed=31):
+    """A consistent LP whose matched basis is a band with kl = `below` and ku = `above`: every column has its large entry in
+    its own row and two small ones `below` rows further down / `above` rows further up; one column per row is basic."""
+    rng = np.random.default_rng(seed)
+    n = per_row * m
+    own = np.arange(n) // per_row
+    rows = np.stack([own, np.clip(own + below, 0, m - 1), np.clip(own - above, 0, m - 1)], axis=1)
+    vals = np.stack([rng.uniform(0.8, 1.2, n), rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n)], axis=1)
+    vals[rows[:, 1] == own, 1] = 0.0
+    vals[rows[:, 2] == own, 2] = 0.0
+    import scipy.sparse as sp
+    A = sp.coo_matrix((vals.ravel(), (rows.ravel(), np.repeat(np.arange(n), 3))), shape=(m, n)).tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    basic = np.zeros(n, dtype=bool)
+    basic[np.arange(m) * per_row + rng.integers(0, per_row, m)] = True
+    x = np.where(basic, rng.uniform(0.1, 1.0, n), 1e-9)
+    y = rng.standard_normal(m)
+    s_d = np.where(basic, 1e-10, np.abs(rng.standard_normal(n)))
+    return workloads.LPInstance(A=A, b=A @ x, c=A.T @ y + s_d, l=np.zeros(n), u=np.full(n, np.inf), sense=np.full(m, "="), x=x, y=y)
+
+
+def test_a_band_between_the_two_width_limits_is_refused_not_crashed(ctx, monkeypatch):
+    """kl + 32 <= 1536 but kl + ku + 32 = 2,024 > 1,980: round 3 accepted this basis in the crossover (limit 2,400) and then
+    failed inside sx_bandlu_create_dev with SX_ERR_INVALID -- a ValueError the 'HIP' backend did not catch.  Both now ask
+    one function (sx_bandlu_supports): SX_ERR_UNSUPPORTED, and the backend falls back on the dense crossover."""
+    from smart_crossover.hip.device import BandLU
+    put = lambda v, t: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    one = (put(np.zeros(1), np.int32), put(np.zeros(1), np.int32), put(np.ones(1), np.float64))
+    BandLU(ctx, 3000, 1000, 900, *one).free()                      # 1,932 rows of LDS window: accepted
+    with pytest.raises(ValueError):
+        BandLU(ctx, 3000, 1000, 992, *one)                         # 2,024: refused by the band LU itself
+    # an LP whose basis has that shape in the natural order of its rows (three diagonals 1,000 below / 960 above): the
+    # crossover either finds a narrower band (its Cuthill-McKee order folds the diagonals together) and solves it, or
+    # refuses -- never the ValueError of round 3; through the backend the vertex is reached on one path or the other
+    inst = wide_band_lp()
+    lt = inst.sense == "<"
+    try:
+        res = direct(ctx, inst.A, inst.b, inst.c, inst.l, inst.u, lt, inst.x)[0]
+        assert int(res.status) == 0
+    except NotImplementedError:
+        pass
+    lp, mgr = perturbed_sub_problem(inst)
+    caller, out = resolve(mgr, inst, monkeypatch, "band")
+    assert caller.solved_by in ("crossover_band", "simplex") and out.status == "OPTIMAL"
+    certificates(mgr.lp_sub, out)
+
+
+@pytest.mark.parametrize("knob", ["window_4096", "uniform_entries"])
+def test_hostile_structure_reaches_highs_optimum_on_one_path_or_the_other(ctx, monkeypatch, knob, record_property):
+    """One case per knob of the generator that round 3 tuned until every basis was a narrow, column-dominant band: a window
+    of 4,096 rows (at 3,000 rows: every column reaches a third of the matrix -> kl + ku ~ 1,100, still a band the LU takes)
+    and entries drawn U(-1, 1) on the same pattern (no dominant own-row entry: ill-conditioned bases, the band LU and the
+    dense LU set columns aside).  Whichever path answers -- the sparse crossover, or the dense one behind its refusal or
+    its failure -- the vertex is HiGHS' and certified; which one it was is recorded."""
+    from smart_crossover.lp_methods import algorithms as alg
+    if knob == "window_4096":
+        inst = workloads.netlib_lp(3000, 30000, seed=12, window=4096)
+    else:
+        base = workloads.netlib_lp(3000, 30000, seed=13)
+        rng = np.random.default_rng(14)
+        A = base.A.copy()
+        A.data = rng.uniform(-1.0, 1.0, A.data.size)
+        slack, s_d = base.b - base.A @ base.x, base.c - base.A.T @ base.y
+        inst = workloads.LPInstance(A=A, b=A @ base.x + slack, c=A.T @ base.y + s_d, l=base.l, u=base.u, sense=base.sense, x=base.x, y=base.y)
+    lp, mgr = perturbed_sub_problem(inst)
+    caller, out = resolve(mgr, inst, monkeypatch, "band")
+    record_property("solved_by", caller.solved_by)
+    print(f"[hostile structure] {knob}: solved by {caller.solved_by}, {int(out.iter_count)} iterations")
+    assert caller.solved_by in ("crossover_band", "simplex") and out.status == "OPTIMAL"
+    sub = mgr.lp_sub
+    certificates(sub, out)
+    lt = np.asarray(sub.sense) == "<"
+    ref = linprog(sub.c, A_ub=sub.A[lt], b_ub=sub.b[lt], A_eq=sub.A[~lt], b_eq=sub.b[~lt], bounds=np.c_[sub.l, sub.u], method="highs")
+    assert ref.status == 0
+    assert float(sub.c @ out.x) == pytest.approx(ref.fun, rel=1e-7, abs=1e-8)
