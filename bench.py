@@ -520,6 +520,8 @@ def main():
     ap.add_argument("--pricing-rounds", type=int, default=50,
                     help="also time this many pricing rounds of a column-sharded simplex pivot (K10 on the rank's block + "
                          "the all-gather of the 24-byte records at N > 1): reported under 'sharded_pricing' (0: skip)")
+    ap.add_argument("--resolve-rows", type=int, default=20000,
+                    help="N > 1 only: rows of the LP of the column-sharded re-solve leg ('sharded_resolve'; 0: skip)")
     ap.add_argument("--c4-highs", action="store_true",
                     help="time config 4's network crossover with the re-solves in HiGHS too (94 s on the box's host cores; "
                          "without it the line quotes profiles/r02/netdual_c4_highs.jsonl)")
@@ -863,6 +865,38 @@ def main():
                       "allreduce_bytes_per_iteration": 8 * m if world > 1 else 0,
                       "algorithmic_GBps_per_gpu": cg_bytes / (cg_elapsed / args.cg_iters) / 1e9}
 
+    # ---- optional at N > 1: the column-sharded LP re-solve (smart_crossover.distributed.ShardedLP.restricted_resolve):
+    # restricted LP replicated and re-solved from its own basis on every rank's GPU (K16s), pricing of the columns
+    # outside it rank-local (K1 walk over the rank's block), one all-gather of the records and one of the entering
+    # columns per round.  Never fatal: a failure is recorded and the line goes out without it
+    sharded_resolve = None
+    if use_dist and not rehearse and args.resolve_rows > 0:
+        try:
+            from smart_crossover import distributed as D
+            from smart_crossover.formats import GeneralLP
+            rr = args.resolve_rows
+            inst2 = workloads.netlib_lp(rr, 10 * rr, seed=17)
+            rng2 = np.random.default_rng(18)
+            lp2 = GeneralLP(inst2.A, inst2.b, inst2.c + 0.3 * rng2.standard_normal(10 * rr), inst2.l,
+                            np.where(np.isinf(inst2.u), 30.0, inst2.u), inst2.sense)
+            sh2 = D.ShardedLP(lp2, dist, D.HipOps(ctx, torch))
+            tr2 = []
+            fence()
+            t_rs = time.perf_counter()
+            x_R, y_R, R_R, basis_R, status_R, rounds_R = sh2.restricted_resolve(np.flatnonzero(inst2.x > 1e-6), solver="HIP", x_start=inst2.x, y_start=inst2.y,
+                                                                                first_method="barrier", batch=2048, opt_tol=1e-6, trace=tr2)
+            fence()
+            rs_elapsed = time.perf_counter() - t_rs
+            tt = torch.tensor([rs_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded_resolve = {"workload": f"netlib_lp({rr}, {10 * rr}) with another cost vector; restricted LP = the point's interior columns",
+                               "status": status_R, "rounds": int(rounds_R), "columns_added": [len(t) for t in tr2],
+                               "seconds": float(tt.item()), "objective": float(lp2.c[R_R] @ x_R) if status_R == "OPTIMAL" else None,
+                               "exchange": f"per round: all_gather of <= 2048 (|rc|, column) records per rank + all_gather of the entering columns, {world} ranks",
+                               "note": "factorisation and tableau replicated (every rank makes the same pivots); pricing sharded"}
+        except Exception as exc:
+            sharded_resolve = {"failed": f"{type(exc).__name__}: {exc}"[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import lp_path as L     # checker / baseline only; never on the product path
@@ -890,6 +924,23 @@ def main():
         if uniform is None:             # free the resident c5 shard before the crossovers allocate theirs
             for a in (dC, dR):
                 a.free()
+        exp = os.environ.get("SX_BENCH_EXPERIMENT", "")   # measurement aids for the in-bench slowdown of get_perturb_problem
+        if "close_ctx" in exp:                             # ... the scoring context (its stream, 4,096 marker events, arrays) gone
+            for name in ("price", "counts", "code", "flag", "s_d", "s_p"):
+                v = locals().get(name)
+                if hasattr(v, "free"):
+                    v.free()
+            ctx.close()
+        if "gc" in exp:                                    # ... the host arrays of the 1e7-column shard released
+            import gc
+            sh = None
+            gc.collect()
+        if "one_thread" in exp:                            # ... numpy's / scipy's worker threads told to stay out
+            os.environ["OMP_NUM_THREADS"] = "1"
+        if os.environ.get("SX_BENCH_ONLY_LP_1E6"):     # profiling aid (tools/gpu/prof_inbench.sh): the headline leg alone, in bench.py's process state
+            rec = _device_lp_crossover(workloads.netlib_lp(), 3, "netlib_lp (the 1e6-variable LP of the metric)")
+            print(json.dumps({"lp_1e6_end_to_end": rec}), flush=True)
+            return
         net_c3, net_mcf = crossover_network(), crossover_mcf()
         net_c4 = crossover_mcf(2 ** 17, 2 ** 20, solvers=("HIP", "HGS") if args.c4_highs else ("HIP",), repeats=1)
         if not args.c4_highs:   # the HiGHS leg as recorded on one of the pool's boxes (same instance, same code path)
@@ -949,6 +1000,7 @@ def main():
             "cpu_baseline": cpu,
             "sharded_cg": sharded_cg,
             "sharded_pricing": sharded_pricing,
+            "sharded_resolve": sharded_resolve,
             "crossover": crossover,
             "result": {"fix_low": int(cnts[0]), "fix_up": int(cnts[1]), "fixed_rows": int(cnts[2]),
                        "min_rc": mn, "argmin": am, "n_violating": bad},

@@ -391,7 +391,7 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
         return SX_OK;
     }
 
-    const int swzT = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
+    const int swzT = sx_csc_swizzle(ctx, A);
     const int swzA = (ctx->opt_xcd_swizzle && A->n_csr_tiles >= 64 && A->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     const int gT = grid_for(ctx, A->n_csc_tiles), gA = grid_for(ctx, A->n_csr_tiles);
     // vector kernels: grid-stride with ~4 elements per lane, at most 1024 workgroups (= partials); a
@@ -475,7 +475,7 @@ SX_API int sx_projector_std_dev(sx_ctx *ctx, const sx_matrix *A, const double *x
         const int batch = 24;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        if (ctx->opt_graph && maxiter >= 2 * batch) {
+        if (ctx->opt_graph && maxiter >= 2 * batch && getenv("SX_NO_GRAPH") == nullptr) { // (SX_NO_GRAPH: direct launches, for traces)
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 for (int k = 0; k < batch; ++k) enqueue_iteration(k & 1);
                 if (hipStreamEndCapture(s, &graph) != hipSuccess || graph == nullptr ||
@@ -652,7 +652,7 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
     h->cs = cs;
     h->tol = tol;
     const int64_t m = h->m = A_loc->m, n = h->n = A_loc->n;
-    h->swzT = (ctx->opt_xcd_swizzle && A_loc->n_csc_tiles >= 64) ? 1 : 0;
+    h->swzT = sx_csc_swizzle(ctx, A_loc);
     h->swzA = (ctx->opt_xcd_swizzle && A_loc->n_csr_tiles >= 64 && A_loc->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     h->gT = grid_for(ctx, A_loc->n_csc_tiles);
     h->gA = grid_for(ctx, A_loc->n_csr_tiles);
@@ -967,7 +967,7 @@ SX_API int sx_projector_free_dev(sx_ctx *ctx, const sx_matrix *A, int64_t nf, co
         ~Guard() { (void)sx_matrix_destroy(M); }
     } guard{A2};
     SX_TRY(sx_gather_f64_dev(ctx, nf, free_idx, c, c_free));
-    const int swzT = (ctx->opt_xcd_swizzle && A2->n_csc_tiles >= 64) ? 1 : 0;
+    const int swzT = sx_csc_swizzle(ctx, A2);
     const int swzA = (ctx->opt_xcd_swizzle && A2->n_csr_tiles >= 64 && A2->csr_imbalance <= SX_SWIZZLE_MAX_IMBALANCE) ? 1 : 0;
     const int gT = grid_for(ctx, A2->n_csc_tiles), gA = grid_for(ctx, A2->n_csr_tiles);
     const dim3 gv = g1(nf);

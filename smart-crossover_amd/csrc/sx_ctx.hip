@@ -126,6 +126,12 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_slabs = static_cast<int>(value);
     } else if (!strcmp(key, "run_prefetch")) {
         ctx->opt_run_prefetch = value ? 1 : 0;
+    } else if (!strcmp(key, "rb_long_xcd")) {
+        SX_REQUIRE(value >= -1 && value <= 1, "rb_long_xcd must be -1 (auto), 0 (never) or 1 (always)");
+        ctx->opt_rb_long_xcd = static_cast<int>(value);
+    } else if (!strcmp(key, "rb_long_rows")) {
+        SX_REQUIRE(value >= 1 && value <= 64, "rb_long_rows must be in [1, 64]");
+        ctx->opt_rb_long_rows = static_cast<int>(value); // (read when a layout is built)
     } else if (!strcmp(key, "rb_stage_long")) {
         ctx->opt_rb_stage_long = value ? 1 : 0; // (read when a layout is built)
     } else if (!strcmp(key, "spx_check")) {

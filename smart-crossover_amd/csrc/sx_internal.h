@@ -97,6 +97,9 @@ struct sx_ctx {
     int opt_spx_pricing = 1; // K16 entering variable: 0 Dantzig (largest reduced cost), 1 Devex reference weights
     int opt_slabs = -1;        // operand slabs of a walk without locality (sx_slabs.h): -1 auto, 0 never, R >= 2: R slabs
     int opt_run_prefetch = 0;  // windowed column walk (K1, K10): loads one step ahead (sx_runwalk.h); 0: tile by tile
+    int opt_rb_long_xcd = -1;  // row-blocked walks: the long-row super-tiles dealt over the XCDs (sx_rowblock.h: order[]): -1 when the
+                               // matrix puts them unevenly, 0 never, 1 always
+    int opt_rb_long_rows = 64; // rows per super-tile of long rows (read when a layout is built; sx_rowblock.h RB_LONG_ROWS)
     int opt_rb_stage_long = 0; // row-blocked layout: products of the long rows by a column-ordered pre-pass (0: gather in the
                                // walk).  Measured SLOWER (K2 0.442 vs 0.381 ms at config 5: the 1e7 scattered 8-byte stores cost more
                                // than the 1e7 gathered lines they replace; profiles/r03/experiments/k2_long_row_staging.md): off
@@ -151,7 +154,10 @@ struct sx_matrix {
     // optional per-tile operand window of the column walk (sx_window.hip), built on first use
     mutable int32_t *csc_win_lo = nullptr;
     mutable int csc_win_tried = 0;
-    mutable int csc_win_useful = 0; // verdict of the auto rule
+    mutable int csc_win_useful = 0; // verdict of the auto rule (sampling; overruled by the timing of sx_lp_kernels.hip window_autotune)
+    mutable int csc_win_tuned = 0;
+    mutable int csc_swizzle_off = 0; // window_autotune: this matrix' column walk is faster WITHOUT the XCD-contiguous tile map
+    mutable int csc_win_local = 0;  // at least half of a tile's sampled indices inside one 4096-row window: the gathers have locality
     // optional column-blocked copy of the rows (sx_rowblock.h), built on first use of a row walk
     mutable struct sx_rowblock *rb = nullptr;
     mutable int rb_tried = 0; // 1: the automatic rule has spoken, 2: so has a forced build
@@ -161,7 +167,7 @@ struct sx_matrix {
 };
 
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
-                    int64_t bound, int32_t **win_lo_out, int *useful_out);
+                    int64_t bound, int32_t **win_lo_out, int *useful_out, int *local_out = nullptr);
 // tiles per window load for A's column walk under ctx's "window" option (0 = plain walk)
 int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out);
 
@@ -176,6 +182,11 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
 // the XCD-contiguous tile map (speed only) is used for a walk unless its ranges are that uneven: long segments that
 // sit together -- the linking rows at the head of an LP -- would all queue on one XCD
 constexpr double SX_SWIZZLE_MAX_IMBALANCE = 1.5;
+// XCD-contiguous tile map of A's COLUMN walks (K1, K10, the CG's column pass): the context's option, unless the timing of
+// window_autotune (sx_lp_kernels.hip) found this matrix faster without it
+inline int sx_csc_swizzle(const sx_ctx *ctx, const sx_matrix *A) {
+    return (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64 && !A->csc_swizzle_off) ? 1 : 0;
+}
 // exclusive scan of in[0..n) into out[0..n] (out[n] = total); uses ctx->ws (sx_compact.hip)
 int sx_scan_exclusive(sx_ctx *ctx, const int64_t *in, int64_t n, int64_t *out);
 

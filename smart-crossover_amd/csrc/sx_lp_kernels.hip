@@ -587,6 +587,63 @@ static int slab_passes(sx_ctx *ctx, const sx_slabs *S, const double *operand) {
 } // namespace
 
 // ====================================================================================== API
+// The LDS operand window of the column walk by MEASUREMENT (option "window" = -1, matrices of >= 2^22 entries, first K1 /
+// K10 call): the sampling rule of sx_window.hip (half of the indices inside the window AND a median extent of >= 1,024 rows)
+// was fitted to the lp_shard staircase, where a narrow window makes the plain walk the faster one (0.305 against 0.329 ms);
+// on netlib_lp at config-5 size (extent ~100 rows, linking rows at the head) the plain walk takes 0.70 ms and the windowed
+// one 0.35 (profiles/r04/experiments/k1_netlib_knobs.txt).  So the two are timed once per matrix with the pricing walk --
+// same entry stream and gathers as K1, no per-column output -- on the operands of the call at hand, and the faster one is
+// kept (results are bit-identical either way).  Not under stream capture.
+int window_autotune(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c) {
+    if (ctx->opt_window >= 0 || A->csc_win_tuned || A->nnz < (1 << 22) || A->n_csc_tiles < 64) return SX_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return SX_OK;
+    }
+    A->csc_win_tuned = 1;
+    int run = 0;
+    SX_TRY(sx_window_run_csc(ctx, A, &run)); // (builds the table)
+    if (!A->csc_win_lo) return SX_OK;
+    int nb = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID);
+    nb &= ~7;
+    if (nb < 8) return SX_OK;
+    SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(PricePartial)));
+    PricePartial *partial = static_cast<PricePartial *>(ctx->ws);
+    hipEvent_t ev[5];
+    for (auto &e : ev) SX_HIP(hipEventCreate(&e));
+    float t[4] = {0.f, 0.f, 0.f, 0.f}; // [swizzle on: plain, windowed; swizzle off: plain, windowed]
+    const int nsw = ctx->opt_xcd_swizzle ? 2 : 1;
+    for (int rep = 0; rep < 2; ++rep) { // (the first round warms all up)
+        SX_HIP(hipEventRecord(ev[0], ctx->stream));
+        for (int k = 0; k < 2 * nsw; ++k) {
+            const int swz = (ctx->opt_xcd_swizzle && k < 2) ? 1 : 0;
+            if ((k & 1) == 0)
+                hipLaunchKernelGGL((k_price<4096, 0>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx,
+                                   A->csc_val, y, c, static_cast<const int8_t *>(nullptr), 1e-6, static_cast<double *>(nullptr), partial,
+                                   static_cast<const double *>(nullptr));
+            else
+                hipLaunchKernelGGL((k_price_lw<4, 0>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr,
+                                   A->csc_idx, A->csc_val, A->m, y, c, static_cast<const int8_t *>(nullptr), 1e-6, static_cast<double *>(nullptr), partial);
+            SX_HIP(hipEventRecord(ev[k + 1], ctx->stream));
+        }
+        SX_HIP(hipEventSynchronize(ev[2 * nsw]));
+        for (int k = 0; k < 2 * nsw; ++k) SX_HIP(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    SX_HIP(hipGetLastError());
+    // the fastest of the (up to) four; the map in force and the rule's own choice win ties of less than 5 %
+    int best = A->csc_win_useful ? 1 : 0;
+    for (int k = 0; k < 2 * nsw; ++k)
+        if (t[k] < 0.95f * t[best]) best = k;
+    A->csc_win_useful = best & 1;
+    A->csc_swizzle_off = (ctx->opt_xcd_swizzle && best >= 2) ? 1 : 0;
+    if (getenv("SX_SPX_TRACE"))
+        fprintf(stderr, "[sx_window] column walk timed on this matrix (ms): XCD map on: plain %.3f, windowed %.3f; off: plain %.3f, windowed %.3f -> %s, map %s\n", t[0], t[1],
+                t[2], t[3], A->csc_win_useful ? "windowed" : "plain", A->csc_swizzle_off ? "off" : "on");
+    return SX_OK;
+}
+
 SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c,
                                 const double *x, const double *l, const double *u, double gamma,
                                 double *s_d, uint8_t *code) {
@@ -597,10 +654,11 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     SX_REQUIRE(y && c, "y or c is NULL");
     SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
     if (A->n == 0) return SX_OK;
-    int run = 0; // LDS operand window (sx_window.h): table built on first use, auto rule decides
+    int run = 0; // LDS operand window (sx_window.h): table built on first use; a large matrix is timed once, else the rule decides
+    SX_TRY(window_autotune(ctx, A, y, c));
     SX_TRY(sx_window_run_csc(ctx, A, &run));
     if (run) {
-        const int swz = ctx->opt_xcd_swizzle;
+        const int swz = sx_csc_swizzle(ctx, A);
 #define SX_LAUNCH_K1W(R)                                                                           \
     do {                                                                                           \
         const int64_t nruns = (A->n_csc_tiles + (R)-1) / (R);                                      \
@@ -639,7 +697,7 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     const unsigned grid = walk_grid(ctx, A->n_csc_tiles);
 #define SX_LAUNCH_K1(CH, NTV)                                                                      \
     hipLaunchKernelGGL((k_score_columns<CH, NTV>), dim3(grid), dim3(SX_WG), 0, ctx->stream,        \
-                       A->csc_tiles, A->n_csc_tiles, ctx->opt_xcd_swizzle, A->csc_ptr, A->csc_idx, \
+                       A->csc_tiles, A->n_csc_tiles, sx_csc_swizzle(ctx, A), A->csc_ptr, A->csc_idx, \
                        A->csc_val, y, c, x, l, u, gamma, s_d, code, static_cast<const double *>(nullptr))
     SX_DISPATCH_VARIANT(ctx, SX_LAUNCH_K1);
 #undef SX_LAUNCH_K1
@@ -760,7 +818,8 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     SX_REQUIRE(A->csc_ptr != nullptr, "matrix has no CSC layout (row shard?)");
     SX_REQUIRE(y && c && result_dev, "y, c or result is NULL");
     // the swizzled walk needs a grid that is a multiple of 8 (one slice per XCD)
-    const int swz = (ctx->opt_xcd_swizzle && A->n_csc_tiles >= 64) ? 1 : 0;
+    SX_TRY(window_autotune(ctx, A, y, c));
+    const int swz = sx_csc_swizzle(ctx, A);
     int nb = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID);
     if (swz) nb &= ~7;
     if (nb == 0) {

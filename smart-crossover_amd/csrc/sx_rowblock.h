@@ -84,6 +84,11 @@ struct sx_rowblock {
     int64_t nl = 0;
     int32_t *lcol = nullptr, *le = nullptr;
     double *lval = nullptr, *lprod = nullptr;
+    // Optional block -> super-tile map of the walks (option "rb_long_xcd", built on first use; sx_rowblock.hip rb_build_order):
+    // the long-row super-tiles dealt over the eight XCDs, the ordinary ones behind them in ascending order.  order[b] < 0: no tile.
+    mutable int32_t *order = nullptr;
+    mutable int64_t order_n = 0;
+    mutable int order_tried = 0;
 };
 
 // Layout of A's rows under ctx's "rowblock" option (-1 auto: built for matrices of >= RB_AUTO_NNZ entries

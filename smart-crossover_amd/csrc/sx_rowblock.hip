@@ -20,6 +20,9 @@
 #include "sx_rowblock.h"
 #include "sx_segwalk.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace {
 
 constexpr int RB_NQ = RB_CHUNK / (RB_TW * 4);   // 16-byte index loads per lane and chunk
@@ -257,13 +260,14 @@ __device__ __forceinline__ void rb_supertile_sum(const RbLayout &L, const sx_rb_
 }
 
 // ------------------------------------------------------------------------------------- K2
-__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_score_rows(RbLayout L, int swizzle, const double *__restrict__ x,
+__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_score_rows(RbLayout L, int swizzle, const int32_t *__restrict__ order,
+                                                                  const double *__restrict__ x,
                                                                   int64_t ncols, const double *__restrict__ b,
                                                                   const double *__restrict__ y, double gamma_dual,
                                                                   double *__restrict__ s_p, uint8_t *__restrict__ flag) {
     __shared__ RbLds lds;
-    const int64_t tile = sx_tile_of_block(blockIdx.x, L.nst, swizzle);
-    if (tile >= L.nst) return;
+    const int64_t tile = order ? static_cast<int64_t>(order[blockIdx.x]) : sx_tile_of_block(blockIdx.x, L.nst, swizzle);
+    if (tile < 0 || tile >= L.nst) return;
     const sx_rb_supertile S = L.st[tile];
     double sum[RB_RPL];
     rb_supertile_sum(L, S, x, ncols, lds, sum);
@@ -291,8 +295,8 @@ struct RbCgState { // leading fields of CgState (sx_cg.hip): only `done` is read
     int converged;
 };
 
-__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swizzle, const RbCgState *st,
-                                                            const double *__restrict__ w, int64_t ncols,
+__global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swizzle, const int32_t *__restrict__ order, int64_t order_n,
+                                                            const RbCgState *st, const double *__restrict__ w, int64_t ncols,
                                                             const double *__restrict__ xs, const double *__restrict__ p,
                                                             double *__restrict__ q, double *__restrict__ partial) {
     if (st->done) return;
@@ -307,8 +311,15 @@ __global__ __launch_bounds__(RB_TW, RB_MINW) void k_rb_cg_a(RbLayout L, int swiz
         t_step = gridDim.x >> 3;
     }
     double dot = 0.0;
+    if (order) { // slots of the dealt map: a block keeps to the slots of its XCD (gridDim.x is a multiple of 8)
+        t = blockIdx.x;
+        t_end = order_n;
+        t_step = gridDim.x;
+    }
     for (; t < t_end; t += t_step) {
-        const sx_rb_supertile S = L.st[t];
+        const int64_t tile = order ? static_cast<int64_t>(order[t]) : t;
+        if (tile < 0) continue;
+        const sx_rb_supertile S = L.st[tile];
         double sum[RB_RPL];
         rb_supertile_sum(L, S, w, ncols, lds, sum);
 #pragma unroll
@@ -388,15 +399,94 @@ inline unsigned rb_lp_grid(int64_t nl) {
 
 } // namespace
 
+namespace {
+// order[] of sx_rowblock.h.  The XCD-contiguous map (block b -> XCD b mod 8 walks the b-th eighth of the super-tiles) keeps
+// the x windows of neighbouring super-tiles in one L2, but it puts the long-row super-tiles -- one lane per linking row, a
+// gather per entry: bound by latency, several times slower than their entry count says -- wherever the matrix has them:
+// linking rows at the head of the LP = all of them on XCD 0 (netlib_lp at config-5 size: K2 0.92 ms against 0.37 ms for
+// the lp_shard staircase, whose eight regions each bring their own).  Here the long super-tiles are DEALT over the eight
+// XCDs, first in dispatch order, and the ordinary ones fill up behind them in ascending order, every XCD to the same cost
+// (entries; a long super-tile counts LONG_COST times).  (Gathering them on ONE XCD so that the x lines they share are
+// fetched once was measured too: 0.90 ms against 0.37 -- that XCD becomes the critical path; profiles/r04/experiments/k2_long_xcd.md.)
+// mode 1: always; -1: only when the natural map is uneven (heaviest XCD's long-tile cost > 1.5 x the mean)
+constexpr double RB_LONG_COST = 3.0;
+int rb_build_order(sx_ctx *ctx, const sx_rowblock *rb, int mode) {
+    rb->order_tried = mode ? mode : 1000;
+    (void)hipFree(rb->order);
+    rb->order = nullptr;
+    rb->order_n = 0;
+    const int64_t nst = rb->nst;
+    if (nst < 64) return SX_OK;
+    std::vector<sx_rb_supertile> st(static_cast<size_t>(nst));
+    std::vector<sx_rb_chunk> ck(static_cast<size_t>(rb->nchunks));
+    SX_HIP(hipMemcpyAsync(st.data(), rb->st, sizeof(sx_rb_supertile) * st.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SX_HIP(hipMemcpyAsync(ck.data(), rb->chunks, sizeof(sx_rb_chunk) * ck.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<double> cost(static_cast<size_t>(nst));
+    std::vector<int32_t> longs, plain;
+    double total = 0.0, nat_long[8] = {0, 0, 0, 0, 0, 0, 0, 0}, long_total = 0.0;
+    const int64_t per_nat = (nst + 7) >> 3;
+    for (int64_t t = 0; t < nst; ++t) {
+        int64_t ne = 0;
+        for (int64_t k = 0; k < st[t].nchunks; ++k) ne += ck[static_cast<size_t>(st[t].chunk0 + k)].ne;
+        const bool is_long = st[t].nrows > 0 && st[t].nrows <= RB_LONG_ROWS && ne > static_cast<int64_t>(RB_LONG_ROW) * st[t].nrows;
+        cost[t] = static_cast<double>(ne) * (is_long ? RB_LONG_COST : 1.0) + 4096.0;
+        total += cost[t];
+        if (is_long) {
+            nat_long[t / per_nat] += cost[t];
+            long_total += cost[t];
+        }
+        (is_long ? longs : plain).push_back(static_cast<int32_t>(t));
+    }
+    if (longs.empty()) return SX_OK; // nothing to deal: the plain map stays
+    if (mode < 0) {
+        double worst = 0.0;
+        for (double v : nat_long) worst = std::max(worst, v);
+        if (worst <= 1.5 * long_total / 8.0) return SX_OK; // the matrix spreads them by itself
+    }
+    std::vector<std::vector<int32_t>> per(8);
+    const double share = total / 8.0;
+    double have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < longs.size(); ++i) {
+        per[i & 7].push_back(longs[i]);
+        have[i & 7] += cost[longs[i]];
+    }
+    int xcd = 0;
+    for (int32_t t : plain) {
+        while (xcd < 7 && have[xcd] + 0.5 * cost[t] > share) ++xcd;
+        per[xcd].push_back(t);
+        have[xcd] += cost[t];
+    }
+    size_t most = 0;
+    for (auto &v : per) most = std::max(most, v.size());
+    std::vector<int32_t> order(most * 8, -1);
+    for (int x = 0; x < 8; ++x)
+        for (size_t k = 0; k < per[x].size(); ++k) order[k * 8 + static_cast<size_t>(x)] = per[x][k];
+    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->order), sizeof(int32_t) * order.size()));
+    SX_HIP(hipMemcpyAsync(rb->order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+    SX_HIP(hipStreamSynchronize(ctx->stream));
+    rb->order_n = static_cast<int64_t>(order.size());
+    return SX_OK;
+}
+const int32_t *rb_order(sx_ctx *ctx, const sx_rowblock *rb) {
+    if (ctx->opt_rb_long_xcd == 0 || !ctx->opt_xcd_swizzle) return nullptr;
+    const int want = ctx->opt_rb_long_xcd;
+    if (rb->order_tried != want && rb_build_order(ctx, rb, want) != SX_OK) return nullptr;
+    return rb->order;
+}
+} // namespace
+
 int sx_rb_score_rows(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const double *x, const double *b,
                      const double *y, double gamma_dual, double *s_p, uint8_t *flag) {
     if (rb->nst == 0) return SX_OK;
     const int swz = ctx->opt_xcd_swizzle;
-    const unsigned grid = swz ? static_cast<unsigned>(((rb->nst + 7) >> 3) << 3) : static_cast<unsigned>(rb->nst);
+    unsigned grid = swz ? static_cast<unsigned>(((rb->nst + 7) >> 3) << 3) : static_cast<unsigned>(rb->nst);
+    const int32_t *order = rb_order(ctx, rb);
+    if (order) grid = static_cast<unsigned>(rb->order_n);
     if (rb->nl > 0)
         hipLaunchKernelGGL(k_rb_long_products, dim3(rb_lp_grid(rb->nl)), dim3(SX_WG), 0, ctx->stream,
                            rb->nl, rb->lcol, rb->lval, rb->le, x, rb->lprod, static_cast<const RbCgState *>(nullptr));
-    hipLaunchKernelGGL(k_rb_score_rows, dim3(grid), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, x, ncols, b, y,
+    hipLaunchKernelGGL(k_rb_score_rows, dim3(grid), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, order, x, ncols, b, y,
                        gamma_dual, s_p, flag);
     SX_HIP(hipGetLastError());
     return SX_OK;
@@ -411,7 +501,8 @@ int sx_rb_cg_a(sx_ctx *ctx, const sx_rowblock *rb, int64_t ncols, const void *cg
     if (rb->nl > 0)
         hipLaunchKernelGGL(k_rb_long_products, dim3(rb_lp_grid(rb->nl)), dim3(SX_WG), 0, ctx->stream,
                            rb->nl, rb->lcol, rb->lval, rb->le, w, rb->lprod, static_cast<const RbCgState *>(cg_state));
-    hipLaunchKernelGGL(k_rb_cg_a, dim3(static_cast<unsigned>(g)), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz,
+    const int32_t *order = swz ? rb_order(ctx, rb) : nullptr;
+    hipLaunchKernelGGL(k_rb_cg_a, dim3(static_cast<unsigned>(g)), dim3(RB_TW), 0, ctx->stream, layout_of(rb), swz, order, rb->order_n,
                        static_cast<const RbCgState *>(cg_state), w, ncols, xs, p, q, partial);
     SX_HIP(hipGetLastError());
     *nparts = static_cast<int>(g);

@@ -283,7 +283,7 @@ struct Temps {
 };
 
 // row cuts of the super-tiles (tools/rb_layout.py::supertile_cuts)
-void make_cuts(const std::vector<int64_t> &rowptr, std::vector<int64_t> &cuts) {
+void make_cuts(const std::vector<int64_t> &rowptr, std::vector<int64_t> &cuts, int64_t long_rows) {
     const int64_t m = static_cast<int64_t>(rowptr.size()) - 1;
     cuts.assign(1, 0);
     auto is_long = [&](int64_t r) { return rowptr[r + 1] - rowptr[r] > RB_LONG_ROW; };
@@ -292,7 +292,7 @@ void make_cuts(const std::vector<int64_t> &rowptr, std::vector<int64_t> &cuts) {
         const bool lg = is_long(a);
         int64_t b = a + 1;
         while (b < m && is_long(b) == lg) ++b;
-        const int64_t lim_rows = lg ? std::min<int64_t>(RB_R, RB_LONG_ROWS) : RB_R;
+        const int64_t lim_rows = lg ? std::min<int64_t>(RB_R, long_rows) : RB_R;
         const int64_t lim_entries = lg ? RB_LONG_BUDGET : RB_BUDGET;
         int64_t row = a;
         while (row < b) {
@@ -315,7 +315,7 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
     SX_HIP(hipMemcpyAsync(rowptr.data(), A->csr_ptr, sizeof(int64_t) * rowptr.size(), hipMemcpyDeviceToHost, s));
     SX_HIP(hipStreamSynchronize(s));
     std::vector<int64_t> cuts;
-    make_cuts(rowptr, cuts);
+    make_cuts(rowptr, cuts, ctx->opt_rb_long_rows);
     const int64_t nst = static_cast<int64_t>(cuts.size()) - 1;
     std::vector<int32_t> slice(static_cast<size_t>(nst), 0);
     int64_t nblk = (n + RB_CWIN - 1) / RB_CWIN;
@@ -489,7 +489,7 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
 
 void sx_rowblock_free(sx_rowblock *rb) {
     if (!rb) return;
-    void *ptrs[9] = {rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->lcol, rb->le, rb->lval, rb->lprod};
+    void *ptrs[10] = {rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->lcol, rb->le, rb->lval, rb->lprod, rb->order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete rb;

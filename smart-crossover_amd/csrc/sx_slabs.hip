@@ -181,7 +181,16 @@ int sx_slabs_get(sx_ctx *ctx, const sx_matrix *A, int which, const sx_slabs **ou
         const int64_t operand = 8 * bound;
         constexpr int64_t SLICE = 3200000; // bytes of operand per slab: measured optimum at config-5 size (kbench_slabs*.txt:
                                            // K1 8 MB / 3, K2 80 MB / 24..28; 4 MB slices no longer stay in a 4 MiB L2)
-        if (operand > SLICE + SLICE / 8 && A->nnz >= (1 << 22)) {
+        // (a column walk whose tiles gather from a narrow range of rows has locality whatever the size of y: the LDS window
+        //  may not pay for it -- sx_window.hip's rule, or the timing of window_autotune -- but slabs are for walks WITHOUT it:
+        //  netlib_lp at config-5 size, plain walk 0.26 ms, three slabs 0.69 ms)
+        bool local = false;
+        if (which == 1) {
+            int run = 0;
+            SX_TRY(sx_window_run_csc(ctx, A, &run)); // (builds the sampling table on first use)
+            local = A->csc_win_local != 0;
+        }
+        if (!local && operand > SLICE + SLICE / 8 && A->nnz >= (1 << 22)) {
             const int64_t want = (operand + SLICE - 1) / SLICE;
             if (want <= 256 && 24 * nseg * want * 4 <= 12 * A->nnz * 5) R = static_cast<int>(want);
         }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(SXL_THREADS) void k_win_lo(const int64_t *__restric
 // *win_lo_out stays NULL when the operand is shorter than a window; *useful_out = 1 when the auto rule
 // (file header) says the windowed walk should pay off on this matrix
 int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int64_t *ptr, const int32_t *idx,
-                    int64_t bound, int32_t **win_lo_out, int *useful_out) {
+                    int64_t bound, int32_t **win_lo_out, int *useful_out, int *local_out) {
     *win_lo_out = nullptr;
     *useful_out = 0;
     if (ntiles == 0 || bound < SXL_CAP) return SX_OK;
@@ -130,6 +130,7 @@ int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int
     }
     std::nth_element(extent.begin(), extent.begin() + ntiles / 2, extent.end());
     *useful_out = (taken > 0 && 2 * covered >= taken && extent[ntiles / 2] >= 1024) ? 1 : 0;
+    if (local_out) *local_out = (taken > 0 && 2 * covered >= taken) ? 1 : 0; // the gathers of a tile cluster: no case for operand slabs
     *win_lo_out = wl;
     return SX_OK;
 }
@@ -142,7 +143,7 @@ int sx_window_run_csc(sx_ctx *ctx, const sx_matrix *A, int *run_out) {
     if (!A->csc_win_tried) {
         A->csc_win_tried = 1;
         SX_TRY(sx_window_setup(ctx, A->csc_tiles, A->n_csc_tiles, A->csc_ptr, A->csc_idx, A->m, &A->csc_win_lo,
-                               &A->csc_win_useful));
+                               &A->csc_win_useful, &A->csc_win_local));
     }
     if (!A->csc_win_lo) return SX_OK;
     if (ctx->opt_window < 0) *run_out = A->csc_win_useful ? 4 : 0;

@@ -189,6 +189,12 @@ class HipOps:
     def price(self, A, y, c, vbasis, tol) -> Tuple[float, int, int]:
         return self.ctx.read_price(self.ctx.price(A, self._w(y), self._w(c), self._w(vbasis), tol, None))
 
+    def dual_slack(self, A, y, c):
+        """c - A^T y of the own column block (the K1 walk, codes off)."""
+        s_d = self.empty(A.shape[1], np.float64)
+        self.ctx.score_columns(A, self._w(y), self._w(c), None, None, None, 0.0, self._w(s_d), None)
+        return s_d
+
     def fixed_rhs(self, A_rows, code_all, u_all, l_all, b_loc, out):
         self.ctx.fixed_rhs(A_rows, self._w(code_all), self._w(u_all), self._w(l_all), self._w(b_loc), self._w(out))
 
@@ -536,6 +542,108 @@ class ShardedLP:
             if head[p] < n and cs <= head[p] < ce:
                 x_loc[head[p] - cs] = xB[p]
         return x_loc, Binv.T @ cB, pivots, status
+
+    # ---- the re-solve over column shards: restricted LP replicated, pricing of everything else rank-local ------------
+    def restricted_resolve(self, start_cols, solver: str = "HIP", x_start: Optional[np.ndarray] = None,
+                           y_start: Optional[np.ndarray] = None, first_method: str = "default", batch: int = 2048,
+                           opt_tol: float = 1e-6, max_rounds: int = 200, trace: Optional[list] = None, settings=None):
+        """The LP re-solve with the COLUMNS sharded (north_star: "columns shard naturally ... all-reduce for the global pricing
+        minimum"; the reference's last step, lp_methods/algorithms.py:69-74, prices all columns inside its solver).  What
+        a vertex needs is m columns out of n: the restricted LP over a column set R (``start_cols`` at first: the columns
+        the crossover left free) is REPLICATED and solved by ``solver`` on every rank from the same start -- the device
+        solvers are deterministic, so every rank holds the same vertex and basis --; what scales with n, the pricing of
+        the columns outside R with the duals of that vertex, is rank-local (K1 walk over the rank's column block, the
+        ``batch`` largest violations kept); ONE all-gather of (|reduced cost|, column) records later every rank knows the
+        same ``batch`` entering columns, their owners hand over the entries (one all-gather of the columns themselves),
+        R grows and the restricted LP is solved again FROM THE BASIS IT HAD (``sx_crossover_band_basis_dev`` factors that
+        very basis; new columns non-basic at a bound).  Ends when no column outside R prices out: the vertex is optimal
+        for the whole LP.  Returns (x over R, y, R, basis over R, status, rounds); ``trace`` collects the columns each
+        round added.  Factorisation and tableau are replicated ("replicas only" for those)."""
+        import scipy.sparse as sp
+        import torch
+        from smart_crossover.formats import GeneralLP
+        from smart_crossover.output import Basis
+        from smart_crossover.solver_caller.caller import SolverSettings
+        from smart_crossover.solver_caller.solving import solve_lp
+        o = self.ops
+        m, cs, ce = self.m, self.cols.start, self.cols.stop
+        world = self.ex.world
+        dev = getattr(o, "device", "cpu")
+        settings = settings if settings is not None else SolverSettings(presolve="on", log_console=0, optimalityTol=opt_tol)
+        A_loc = self._host_cols()
+        c_all = self._c_host
+        l_all, u_all = np.asarray(o.host(self.l_all), dtype=np.float64), np.asarray(o.host(self.u_all), dtype=np.float64)
+        l_loc, u_loc = l_all[cs:ce], u_all[cs:ce]
+        sense = np.where(self.lt, "<", "=")
+
+        def fetch(ids: np.ndarray):
+            """m x len(ids) block of the columns ``ids`` (ascending, the same on every rank), each from its owner."""
+            mine = ids[(ids >= cs) & (ids < ce)]
+            piece = sp.csc_matrix(A_loc[:, mine - cs])
+            payload = (mine.size, piece.indptr.astype(np.int64), piece.indices.astype(np.int32), piece.data.astype(np.float64))
+            parts = [payload]
+            if self.dist is not None:
+                parts = [None] * world
+                self.dist.all_gather_object(parts, payload)
+            blocks = [sp.csc_matrix((d, i, p), shape=(m, k)) for (k, p, i, d) in parts if k > 0]     # rank order = column order
+            return sp.hstack(blocks, format="csc") if blocks else sp.csc_matrix((m, 0))
+
+        in_R = np.zeros(self.n, dtype=bool)
+        in_R[np.asarray(start_cols, dtype=np.int64)] = True
+        R = np.flatnonzero(in_R)
+        A_R = fetch(R)
+        basis, x_R, y, status, rounds = None, None, None, "UNKNOWN", 0
+        for rounds in range(1, max_rounds + 1):
+            lp_R = GeneralLP(sp.csr_matrix(A_R), self._b_host, c_all[R], l_all[R], u_all[R], sense)
+            if basis is None:
+                ws = (np.clip(np.asarray(x_start)[R], l_all[R], u_all[R]), y_start) if x_start is not None and y_start is not None else None
+                out = solve_lp(lp_R, solver, first_method, settings, warm_start_solution=ws)
+            else:
+                out = solve_lp(lp_R, solver, "primal_simplex", settings, warm_start_basis=basis, warm_start_solution=(x_R, y))
+            status = out.status
+            if status != "OPTIMAL":
+                break
+            x_R, y, basis = np.asarray(out.x, dtype=np.float64), np.asarray(out.y, dtype=np.float64), out.basis
+            # ---- rank-local pricing of the own columns outside R: non-basic at the lower bound (at the upper one when there
+            #      is no lower), reduced cost of the wrong sign = may enter
+            rc = np.asarray(o.host(o.dual_slack(self.A_cols, o.vec(y), self.c_loc)), dtype=np.float64)
+            at_up = ~np.isfinite(l_loc) & np.isfinite(u_loc)
+            free = ~np.isfinite(l_loc) & ~np.isfinite(u_loc)
+            wrong = np.where(free, np.abs(rc) > opt_tol, np.where(at_up, rc > opt_tol, rc < -opt_tol))
+            cand = np.flatnonzero(wrong & ~in_R[cs:ce] & (l_loc != u_loc))
+            order = np.lexsort((cand, -np.abs(rc[cand])))[:batch]            # largest violation first, ties to the smaller column
+            ids_loc, score_loc = (cand[order] + cs).astype(np.int64), np.abs(rc[cand[order]])
+            # ---- ONE exchange of the records: every rank ends with the same global list
+            cnt = self._allgather(torch.tensor([ids_loc.size], dtype=torch.int64, device=dev), [1] * world)
+            sizes = [int(v) for v in cnt.cpu()]
+            ids_all = self._allgather(torch.from_numpy(ids_loc).to(dev), sizes).cpu().numpy()
+            score_all = self._allgather(torch.from_numpy(np.ascontiguousarray(score_loc)).to(dev), sizes).cpu().numpy()
+            if ids_all.size == 0:
+                break                                                        # optimal for the whole LP
+            pick = np.lexsort((ids_all, -score_all))[:batch]
+            add = np.sort(ids_all[pick])
+            if trace is not None:
+                trace.append([int(j) for j in add])
+            # ---- the entering columns from their owners; R stays in ascending order
+            A_add = fetch(add)
+            in_R[add] = True
+            R_new = np.flatnonzero(in_R)
+            where_old, where_add = np.searchsorted(R_new, R), np.searchsorted(R_new, add)
+            merged = sp.hstack([A_R, A_add], format="csc")
+            perm = np.empty(R_new.size, dtype=np.int64)
+            perm[where_old] = np.arange(R.size)
+            perm[where_add] = R.size + np.arange(add.size)
+            A_R = merged[:, perm]
+            vb = np.empty(R_new.size, dtype=np.int64)
+            vb[where_old] = basis.vbasis
+            up_new = ~np.isfinite(l_all[add]) & np.isfinite(u_all[add])
+            vb[where_add] = np.where(up_new, -2, -1)
+            x_new = np.empty(R_new.size)
+            x_new[where_old] = x_R
+            bound = np.where(up_new, u_all[add], l_all[add])
+            x_new[where_add] = np.where(np.isfinite(bound), bound, 0.0)
+            basis, x_R, R = Basis(vb, basis.cbasis), x_new, R_new
+        return x_R, y, R, basis, status, rounds
 
     def _host_cols(self):
         import scipy.sparse as sp

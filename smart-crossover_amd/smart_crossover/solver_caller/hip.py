@@ -53,9 +53,10 @@ def _pdlp_iterations(m: int, to_band: bool) -> int:
     if not to_band:
         return PDLP_ITERS
     return max(5000, min(PDLP_ITERS, m // 20))
-BAND_MIN_ROWS = 30000    # from this many rows on the crossover behind the first-order stage is the sparse one (K16s:
-                         # band LU of the starting basis + tableau of the tracked columns) when the basis has that
-                         # structure; below, the dense inverse of K16 (8 m^2 bytes) is cheaper to set up
+BAND_MIN_ROWS = 2000     # from this many rows on the crossover behind the first-order stage (and the warm-started simplex) is the
+                         # sparse one (K16s: bordered band factorisation + tableau of the tracked columns) when the basis has
+                         # that structure: 0.054 s against 0.078 s for the dense K16 at 3,000 rows, 0.12 s against 1.03 s at
+                         # 20,000 (netlib_lp, profiles/r04/lp_1e6.md); an unstructured basis is refused after the matching
 NETDUAL_FEAS_TOL = 1e-9  # bound violation of a tree arc the dual network simplex still calls feasible
 CRASH_MARGIN = 1e-6      # a column this far (relative) inside its bounds / a slack this large counts as basic
 

@@ -52,6 +52,9 @@ class OracleOps:
         j = int(np.argmin(rc))
         return (float(rc[j]), j, int(np.count_nonzero(~(rc >= -tol))))
 
+    def dual_slack(self, A, y, c):
+        return torch.from_numpy(L.dual_slack(A.csr, c.numpy(), y.numpy()))
+
     def fixed_rhs(self, A_rows, code_all, u_all, l_all, b_loc, out):
         code = code_all.numpy()
         up, low = np.flatnonzero(code & 2), np.flatnonzero((code & 1) & ~((code & 2) >> 1))

@@ -1,0 +1,71 @@
+"""Worker of the gloo rehearsal of the column-sharded re-solve (TEST INFRASTRUCTURE): ShardedLP.restricted_resolve over
+`world` ranks -- restricted LP replicated (solved by HiGHS here, by the device solvers on the GPU), pricing of the other
+columns rank-local (played by the CPU oracle), one all-gather of the pricing records and one of the entering columns per
+round; rank 0 writes the rounds' columns and the optimum."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "smart-crossover_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import workloads                               # noqa: E402
+from smart_crossover import distributed as D   # noqa: E402
+from smart_crossover.formats import GeneralLP  # noqa: E402
+from _dist_ops import OracleOps                # noqa: E402
+
+
+def problem(m=600, n=6000, seed=17):
+    """A netlib-style LP and another cost vector, so that the columns the start leaves free are not the optimum's."""
+    inst = workloads.netlib_lp(m, n, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    c = inst.c + 0.3 * rng.standard_normal(n)
+    u = np.where(np.isinf(inst.u), 30.0, inst.u)
+    lp = GeneralLP(inst.A, inst.b, c, inst.l, u, inst.sense)
+    start = np.flatnonzero(inst.x > 1e-6)          # the interior columns of the point: a feasible restricted LP
+    problem.point = (inst.x, inst.y)
+    return lp, start
+
+
+def make_ops():
+    if os.environ.get("SX_DIST_OPS", "oracle") == "hip":      # the real kernels, every rank on GPU 0 (tests/test_gpu_dist.py)
+        import torch
+        from smart_crossover.hip import Context
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        return D.HipOps(Context(0, stream.cuda_stream), torch)
+    return OracleOps()
+
+
+def main():
+    out_path, batch = sys.argv[1], int(os.environ.get("SX_TEST_BATCH", "64"))
+    solver = os.environ.get("SX_TEST_SOLVER", "HGS")
+    single = os.environ.get("WORLD_SIZE", "1") == "1"
+    if not single:
+        dist.init_process_group("gloo")
+    size = [int(v) for v in os.environ.get("SX_TEST_SIZE", "600,6000").split(",")]
+    lp, start = problem(*size)
+    sh = D.ShardedLP(lp, None if single else dist, make_ops())
+    trace = []
+    kw = {}
+    if solver == "HIP":      # the device's first solve starts at the point (first-order stage + sparse crossover), not at the slack basis
+        kw = {"x_start": problem.point[0], "y_start": problem.point[1], "first_method": "barrier"}
+    x_R, y, R, basis, status, rounds = sh.restricted_resolve(start, solver=solver, batch=batch, opt_tol=1e-7, trace=trace, **kw)
+    res = {"world": 1 if single else dist.get_world_size(), "status": status, "rounds": rounds, "trace": trace,
+           "obj": float(lp.c[R] @ x_R), "R": [int(j) for j in R], "basic": [int(j) for j in R[basis.vbasis == 0]]}
+    if single or dist.get_rank() == 0:
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    if not single:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,3 +119,29 @@ def test_column_sharded_simplex_makes_the_single_process_pivots(tmp_path):
         assert res["world"] == world and res["status"] == "OPTIMAL"
         assert res["pivots"] == single["pivots"]
         assert res["obj"] == pytest.approx(single["obj"], rel=1e-12)
+
+
+def test_column_sharded_re_solve_adds_the_single_process_columns(tmp_path):
+    """ShardedLP.restricted_resolve: the restricted LP replicated, the pricing of the columns outside it rank-local, one
+    all-gather of (|reduced cost|, column) records and one of the entering columns per round.  Two and three gloo ranks
+    add exactly the columns of the single process in the same rounds (several rounds of at most 64 columns), end on
+    its basis, and the optimum is HiGHS' optimum of the whole LP."""
+    import importlib.util
+    import numpy as np
+    from scipy.optimize import linprog
+    env = {"SX_TEST_BATCH": "64"}
+    single = run_workers("_dist_worker4.py", tmp_path / "w1.json", 1, env)
+    assert single["status"] == "OPTIMAL" and single["rounds"] >= 3 and all(0 < len(t) <= 64 for t in single["trace"])
+    spec = importlib.util.spec_from_file_location("w4", os.path.join(HERE, "_dist_worker4.py"))
+    w4 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w4)
+    lp, start = w4.problem()
+    lt = np.asarray(lp.sense) == "<"
+    ref = linprog(lp.c, A_ub=lp.A[lt], b_ub=lp.b[lt], A_eq=lp.A[~lt], b_eq=lp.b[~lt], bounds=np.c_[lp.l, lp.u], method="highs")
+    assert ref.status == 0 and single["obj"] == pytest.approx(ref.fun, rel=1e-8, abs=1e-8)
+    for world in (2, 3):
+        res = run_workers("_dist_worker4.py", tmp_path / f"w{world}.json", world, env)
+        assert res["world"] == world and res["status"] == "OPTIMAL"
+        assert res["trace"] == single["trace"] and res["R"] == single["R"]
+        assert res["basic"] == single["basic"]
+        assert res["obj"] == pytest.approx(single["obj"], rel=1e-12)

@@ -83,3 +83,29 @@ def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
     b = json.loads(dist.stdout.decode().strip().splitlines()[-1])
     assert a["result"] == b["result"] and b["result"]["fix_low"] > 0
     assert b["n_gpus"] == 1 and b["sharded_cg"]["iterations"] == 5
+
+
+def test_column_sharded_re_solve_on_the_device(tmp_path):
+    """ShardedLP.restricted_resolve with the real kernels and the device solvers: two ranks on GPU 0, the restricted LP
+    (2,400 rows: the sparse crossover's size) replicated and re-solved from its own basis each round
+    (sx_crossover_band_basis_dev), pricing of the other columns by the K1 walk over each rank's block, records and entering
+    columns exchanged over gloo.  Same rounds, same columns, same basis as one process; HiGHS' optimum of the whole LP."""
+    import importlib.util
+    import numpy as np
+    from scipy.optimize import linprog
+    sys.path.insert(0, HERE)
+    from test_dist_gloo import run_workers
+    env = {"SX_DIST_OPS": "hip", "SX_TEST_SOLVER": "HIP", "SX_TEST_SIZE": "2400,24000", "SX_TEST_BATCH": "128",
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LOCAL_RANK": "0"}
+    single = run_workers("_dist_worker4.py", tmp_path / "w1.json", 1, env)
+    assert single["status"] == "OPTIMAL" and single["rounds"] >= 2
+    res = run_workers("_dist_worker4.py", tmp_path / "w2.json", 2, env)
+    assert res["world"] == 2 and res["status"] == "OPTIMAL"
+    assert res["trace"] == single["trace"] and res["R"] == single["R"] and res["basic"] == single["basic"]
+    spec = importlib.util.spec_from_file_location("w4", os.path.join(HERE, "_dist_worker4.py"))
+    w4 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w4)
+    lp, start = w4.problem(2400, 24000)
+    lt = np.asarray(lp.sense) == "<"
+    ref = linprog(lp.c, A_ub=lp.A[lt], b_ub=lp.b[lt], A_eq=lp.A[~lt], b_eq=lp.b[~lt], bounds=np.c_[lp.l, lp.u], method="highs")
+    assert ref.status == 0 and res["obj"] == pytest.approx(ref.fun, rel=1e-7, abs=1e-7)
