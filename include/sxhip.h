@@ -116,6 +116,12 @@ int sx_marker_record(sx_ctx *ctx, int id);
 int sx_marker_elapsed(sx_ctx *ctx, int id_from, int id_to, float *ms_out);
 /* hipDeviceSynchronize on the context's device (all streams) */
 int sx_ctx_sync_device(sx_ctx *ctx);
+/* One big device block per context, kept between calls and allocated AHEAD of its use on a helper thread: the sparse
+ * crossover (sx_crossover_band_*_dev) carves its eta file and tableau out of it -- hipMalloc of the 28 GB it needs at 1e6
+ * rows takes 0.5-1.4 s, which a caller hides behind the first-order stage by asking for the block first.  Returns at once;
+ * a block of that size already held or on its way: nothing happens; bytes = 0 frees what the context holds; a request
+ * beyond 60 % of the free memory is ignored (the call then allocates what it can by itself). */
+int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes);
 
 /* ------------------------------------------------------------------ matrix */
 /* Upload an m x n matrix.  Host CSR arrays are required (the reference keeps A as scipy CSR,

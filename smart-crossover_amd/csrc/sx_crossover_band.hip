@@ -885,24 +885,29 @@ inline unsigned gridcap(int64_t n) { return static_cast<unsigned>(std::min<int64
 
 // The two big blocks of an epoch -- eta file and tableau, tens of GB at 1e6 rows -- out of ONE block that a helper thread
 // allocates while the host matches columns to rows: hipMalloc of a block that size takes as long as the matching itself
-// (0.24 s for 12 GB + ~0.3 s for 16 GB at config-5 size, measured between two trace lines with nothing else in them)
+// (0.5-1.4 s for the 28 GB of config-5 size, box by box; sx_internal.h: the context keeps the block between calls and a
+// backend can ask for it before its first-order stage)
 struct BigArena {
+    sx_ctx *ctx = nullptr;
     void *base = nullptr;
     size_t bytes = 0, used = 0;
-    int device = 0;
-    std::thread th;
-    void start(int dev, size_t want) {
-        device = dev;
+    bool started = false;
+    // the context's block when it is there (a backend that asked for it ahead of the call, or the last call's), else a
+    // prefetch of our own, taken when it is first needed
+    void start(sx_ctx *c, size_t want) {
+        ctx = c;
+        started = true;
+        if (sx_ctx_take_block(ctx, want - want / 3, &base, &bytes)) return; // (a block a third short of the estimate will do)
         bytes = want;
-        th = std::thread([this]() {
-            if (hipSetDevice(device) != hipSuccess || hipMalloc(&base, bytes) != hipSuccess) {
-                base = nullptr;
-                (void)hipGetLastError();
-            }
-        });
+        (void)sx_ctx_prefetch_block(ctx, want);
     }
     void join() {
-        if (th.joinable()) th.join();
+        if (started && !base) {
+            size_t got = 0;
+            if (sx_ctx_take_block(ctx, bytes - bytes / 3, &base, &got)) bytes = got;
+            else bytes = 0;
+            started = false;
+        }
     }
     void *take(size_t n) { // nullptr: no room (the caller allocates for itself)
         join();
@@ -915,7 +920,7 @@ struct BigArena {
     void reset() { used = 0; }
     ~BigArena() {
         join();
-        (void)hipFree(base);
+        if (ctx && base) sx_ctx_give_block(ctx, base, bytes); // (kept for the next call of the process)
     }
 };
 
@@ -1229,17 +1234,20 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] m=%lld n=%lld: %zu interior candidates, band rows %lld, dense rows %lld\n", (long long)m, (long long)n, cand.size(), (long long)m1, (long long)ndr);
     }
+    if (trace) fprintf(stderr, "[sx_crossover_band] host copies, row order and first basic set at %.1f ms\n", now() - t_begin);
     // ------------------------------------------------------------------ the big blocks, allocated beside the matching
     BigArena arena;
     {
         size_t free_b = 0, total_b = 0;
         SX_HIP(hipMemGetInfo(&free_b, &total_b));
+        // (estimates before the matching: border = dense rows + up to 32 separators of ~128 rows; a twelfth of the border is
+        //  set aside by the dense LU of a guess -- 1,032 of 13,771 at config-5 size, 158 of 2,299 at the headline size)
         const double mp_est = static_cast<double>(m) + static_cast<double>(ndr) + 33.0 * 400.0 + 2048.0;
-        const double nb_est = static_cast<double>(ndr) + 32.0 * 240.0 + 1024.0;
-        const double track_est = static_cast<double>(tracked.size()) + nb_est / 8.0;
-        const double epoch_est = std::min(std::min(20000.0, std::min(16.0e9, 0.4 * static_cast<double>(free_b)) / (8.0 * mp_est)), 4.0 * track_est + 2048.0);
-        const double want = 8.0 * mp_est * (epoch_est + 2.0 + 1.6 * track_est + 600.0);
-        if (want > 2.0e9 && want < 0.6 * static_cast<double>(free_b) && !getenv("SX_BAND_NO_ARENA")) arena.start(ctx->device, static_cast<size_t>(want));
+        const double nb_est = static_cast<double>(ndr) + 32.0 * 128.0 + 1024.0;
+        const double track_est = static_cast<double>(tracked.size()) + nb_est / 12.0;
+        const double epoch_est = std::min(std::min(20000.0, std::min(16.0e9, 0.4 * static_cast<double>(free_b)) / (8.0 * mp_est)), 4.0 * (track_est + nb_est / 8.0) + 2048.0);
+        const double want = 8.0 * mp_est * (epoch_est + 2.0 + 1.5 * track_est + 712.0);
+        if (want > 2.0e9 && want < 0.6 * static_cast<double>(free_b) && !getenv("SX_BAND_NO_ARENA")) arena.start(ctx, static_cast<size_t>(want));
     }
     // ------------------------------------------------------------------ small per-call blocks
     TbState *d_st = nullptr;
@@ -1297,27 +1305,10 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                 int32_t ib;
                 int64_t var;
             };
-            std::vector<Ent> ents;
-            for (int64_t j = 0; j < n; ++j) {
-                if (!is_basic[j] || placed[j]) continue;
-                const size_t first = ents.size();
-                for (int64_t k = cptr[j]; k < cptr[j + 1]; ++k) {
-                    const int32_t ib = rowb[cidx[k]];
-                    const double a = std::fabs(cval[k]);
-                    if (ib >= 0 && bvar[ib] < 0 && a > 1e-6) ents.push_back(Ent{a, ib, j});
-                }
-                // a column's candidates by band row (a handful: insertion sort), so that the stable sort below leaves
-                // equal sizes in (variable, band row) order
-                for (size_t q = first + 1; q < ents.size(); ++q) {
-                    const Ent e = ents[q];
-                    size_t r = q;
-                    for (; r > first && ents[r - 1].ib > e.ib; --r) ents[r] = ents[r - 1];
-                    ents[r] = e;
-                }
-            }
-            {   // order: size descending, then variable, then band row -- a stable LSD radix sort on the inverted bits of
-                // the (positive, finite or infinite) size, 16 bits a pass: 8e5 candidates in ~10 ms against ~40 for
-                // std::sort with the three-way comparison
+            // order: size descending, then variable, then band row -- a stable LSD radix sort on the inverted bits of the
+            // (positive, finite or infinite) size, 16 bits a pass (8e5 candidates in ~10 ms against ~40 for std::sort with the
+            // three-way comparison) -- then every candidate in that order takes its row if both are still free
+            auto place_sorted = [&](std::vector<Ent> &ents) {
                 std::vector<Ent> tmp(ents.size());
                 std::vector<uint32_t> hist(65536);
                 auto key = [](const Ent &e) {
@@ -1338,13 +1329,49 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                     for (const Ent &e : ents) tmp[hist[(key(e) >> sh) & 0xFFFF]++] = e;
                     ents.swap(tmp);
                 }
-            }
-            for (const Ent &e : ents)
-                if (!placed[e.var] && bvar[e.ib] < 0) {
-                    bvar[e.ib] = e.var;
-                    placed[e.var] = 1;
+                for (const Ent &e : ents)
+                    if (!placed[e.var] && bvar[e.ib] < 0) {
+                        bvar[e.ib] = e.var;
+                        placed[e.var] = 1;
+                    }
+            };
+            // Two rounds (the one sort over every entry of every column was 0.16 of the 0.41 s this set-up took at 1e6 rows:
+            // 7e6 candidates of 24 bytes, four passes): first every column's LARGEST entry in a free row competes -- one
+            // candidate per column, and in a column-dominant basis the winner nearly everywhere --, then the columns that lost
+            // theirs compete with all their entries for the rows that are left
+            std::vector<Ent> ents;
+            for (int64_t j = 0; j < n; ++j) {
+                if (!is_basic[j] || placed[j]) continue;
+                Ent best{0.0, -1, j};
+                for (int64_t k = cptr[j]; k < cptr[j + 1]; ++k) {
+                    const int32_t ib = rowb[cidx[k]];
+                    const double a = std::fabs(cval[k]);
+                    if (ib >= 0 && bvar[ib] < 0 && a > 1e-6 && (a > best.a || (a == best.a && ib < best.ib))) best = Ent{a, ib, j};
                 }
+                if (best.ib >= 0) ents.push_back(best);
+            }
+            place_sorted(ents);
+            ents.clear();
+            for (int64_t j = 0; j < n; ++j) {
+                if (!is_basic[j] || placed[j]) continue;
+                const size_t first = ents.size();
+                for (int64_t k = cptr[j]; k < cptr[j + 1]; ++k) {
+                    const int32_t ib = rowb[cidx[k]];
+                    const double a = std::fabs(cval[k]);
+                    if (ib >= 0 && bvar[ib] < 0 && a > 1e-6) ents.push_back(Ent{a, ib, j});
+                }
+                // a column's candidates by band row (a handful: insertion sort), so that the stable sort leaves equal sizes
+                // in (variable, band row) order
+                for (size_t q = first + 1; q < ents.size(); ++q) {
+                    const Ent e = ents[q];
+                    size_t r = q;
+                    for (; r > first && ents[r - 1].ib > e.ib; --r) ents[r] = ents[r - 1];
+                    ents[r] = e;
+                }
+            }
+            place_sorted(ents);
         }
+        if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: columns matched to rows at %.1f ms\n", epochs, now() - t_begin);
         // ---------------------------------------------------------------- blocks: the band cut at SEPARATORS
         // A panel of the band LU is a chain of 32 dependent column steps on one workgroup (53 us at kl + ku = 230), a band of
         // 1e5 rows 3,100 of them in a row.  Cut every RL + W positions: W = max(kl, ku) positions (rows AND the columns matched
@@ -1414,6 +1441,9 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
         // band triplets (a placeholder or a logical: the unit vector of the row), band widths
         std::vector<int32_t> trow, tcol;
         std::vector<double> tval;
+        trow.reserve(static_cast<size_t>(A->nnz) / 2 + static_cast<size_t>(m1));
+        tcol.reserve(trow.capacity());
+        tval.reserve(trow.capacity());
         int kl = 0, ku = 0;
         for (int64_t p = 0; p < m1; ++p) {
             const int64_t v = bvar[p];

@@ -61,10 +61,84 @@ SX_API int sx_ctx_create(int device, void *stream, sx_ctx **out) {
     return SX_OK;
 }
 
+namespace {
+void blk_join(sx_ctx *ctx) { // a pending allocation becomes the context's block (the larger of the two stays)
+    if (!ctx->blk_thread) return;
+    ctx->blk_thread->join();
+    delete ctx->blk_thread;
+    ctx->blk_thread = nullptr;
+    void *p = ctx->blk_pending;
+    const size_t b = ctx->blk_pending_bytes;
+    ctx->blk_pending = nullptr;
+    ctx->blk_pending_bytes = 0;
+    if (p) sx_ctx_give_block(ctx, p, b);
+}
+} // namespace
+
+bool sx_ctx_take_block(sx_ctx *ctx, size_t bytes, void **base, size_t *got) {
+    blk_join(ctx);
+    if (!ctx->blk || ctx->blk_bytes < bytes) return false;
+    *base = ctx->blk;
+    *got = ctx->blk_bytes;
+    ctx->blk = nullptr;
+    ctx->blk_bytes = 0;
+    return true;
+}
+
+void sx_ctx_give_block(sx_ctx *ctx, void *base, size_t bytes) {
+    if (!base) return;
+    if (ctx->blk && ctx->blk_bytes >= bytes) {
+        (void)hipFree(base);
+        return;
+    }
+    if (ctx->blk) (void)hipFree(ctx->blk);
+    ctx->blk = base;
+    ctx->blk_bytes = bytes;
+}
+
+// Start allocating a block of `bytes` on a helper thread (returns at once); the sparse crossover takes it when it starts.
+// A block of that size already there, or on its way: nothing to do.  bytes = 0: free what the context holds.
+SX_API int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes) {
+    SX_ENTER(ctx);
+    if (bytes == 0) {
+        blk_join(ctx);
+        if (ctx->blk) (void)hipFree(ctx->blk);
+        ctx->blk = nullptr;
+        ctx->blk_bytes = 0;
+        return SX_OK;
+    }
+    if (ctx->blk_thread && ctx->blk_pending_bytes >= bytes) return SX_OK;
+    blk_join(ctx);
+    if (ctx->blk && ctx->blk_bytes >= bytes) return SX_OK;
+    size_t free_b = 0, total_b = 0;
+    SX_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (ctx->blk) { // (replaced by the larger one: its memory counts as free)
+        (void)hipFree(ctx->blk);
+        free_b += ctx->blk_bytes;
+        ctx->blk = nullptr;
+        ctx->blk_bytes = 0;
+    }
+    if (static_cast<double>(bytes) > 0.6 * static_cast<double>(free_b)) return SX_OK; // (the call allocates what it can by itself)
+    ctx->blk_pending_bytes = bytes;
+    const int device = ctx->device;
+    ctx->blk_thread = new (std::nothrow) std::thread([ctx, device, bytes]() {
+        void *p = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+        }
+        ctx->blk_pending = p;
+    });
+    if (!ctx->blk_thread) ctx->blk_pending_bytes = 0;
+    return SX_OK;
+}
+
 SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     if (!ctx) return SX_OK;
     sx_device_guard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    blk_join(ctx);
+    if (ctx->blk) (void)hipFree(ctx->blk);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->ws3) (void)hipFree(ctx->ws3);

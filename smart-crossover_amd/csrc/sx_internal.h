@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "sxhip.h"
@@ -72,6 +73,15 @@ struct sx_ctx {
     // large heap); into pinned memory it runs at link speed and the memcpy out of it at memory speed
     void *pin = nullptr;
     size_t pin_half = 0;
+    // one big device block kept between calls and allocatable AHEAD of its use on a helper thread (sx_ctx_prefetch_block):
+    // hipMalloc of tens of GB takes 25-50 ms per GB (0.5-1.4 s for the 28 GB of eta file + tableau the sparse crossover needs
+    // at 1e6 rows), longer than the host work it could hide behind inside the call -- the backend asks for it before the
+    // first-order stage, and a second call of a process finds it still there
+    void *blk = nullptr;
+    size_t blk_bytes = 0;
+    std::thread *blk_thread = nullptr; // allocating blk_pending (blk_pending_bytes)
+    void *blk_pending = nullptr;
+    size_t blk_pending_bytes = 0;
     // timers
     hipEvent_t t0[8];
     hipEvent_t t1[8];
@@ -106,6 +116,10 @@ struct sx_ctx {
 };
 
 int sx_reserve(sx_ctx *ctx, size_t bytes);  // ensure ctx->ws holds >= bytes
+// the context's big block (sx_ctx.hip): take hands it to the caller when it holds >= bytes (waits for a pending
+// allocation; false: none of that size), give hands one back (the larger of the two is kept)
+bool sx_ctx_take_block(sx_ctx *ctx, size_t bytes, void **base, size_t *got);
+void sx_ctx_give_block(sx_ctx *ctx, void *base, size_t bytes);
 int sx_reserve2(sx_ctx *ctx, size_t bytes); // ensure ctx->ws2 holds >= bytes
 int sx_reserve3(sx_ctx *ctx, size_t bytes); // ensure ctx->ws3 holds >= bytes
 

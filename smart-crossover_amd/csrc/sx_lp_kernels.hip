@@ -591,10 +591,11 @@ static int slab_passes(sx_ctx *ctx, const sx_slabs *S, const double *operand) {
 // K10 call): the sampling rule of sx_window.hip (half of the indices inside the window AND a median extent of >= 1,024 rows)
 // was fitted to the lp_shard staircase, where a narrow window makes the plain walk the faster one (0.305 against 0.329 ms);
 // on netlib_lp at config-5 size (extent ~100 rows, linking rows at the head) the plain walk takes 0.70 ms and the windowed
-// one 0.35 (profiles/r04/experiments/k1_netlib_knobs.txt).  So the two are timed once per matrix with the pricing walk --
-// same entry stream and gathers as K1, no per-column output -- on the operands of the call at hand, and the faster one is
-// kept (results are bit-identical either way).  Not under stream capture.
-int window_autotune(sx_ctx *ctx, const sx_matrix *A, const double *y, const double *c) {
+// one 0.35 (profiles/r04/experiments/k1_netlib_knobs.txt).  So the variants -- plain / windowed, with / without the
+// XCD-contiguous tile map -- are timed once per matrix with the very kernel of the first K1 or K10 call, on its own operands
+// (writing its outputs four times over), and the fastest is kept; results are bit-identical either way.  Not under capture.
+template <class Launch> // launch(windowed, swizzle): enqueues the calling walk's kernel in that variant
+int window_autotune(sx_ctx *ctx, const sx_matrix *A, Launch launch) {
     if (ctx->opt_window >= 0 || A->csc_win_tuned || A->nnz < (1 << 22) || A->n_csc_tiles < 64) return SX_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
@@ -605,26 +606,14 @@ int window_autotune(sx_ctx *ctx, const sx_matrix *A, const double *y, const doub
     int run = 0;
     SX_TRY(sx_window_run_csc(ctx, A, &run)); // (builds the table)
     if (!A->csc_win_lo) return SX_OK;
-    int nb = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID);
-    nb &= ~7;
-    if (nb < 8) return SX_OK;
-    SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb) * sizeof(PricePartial)));
-    PricePartial *partial = static_cast<PricePartial *>(ctx->ws);
     hipEvent_t ev[5];
     for (auto &e : ev) SX_HIP(hipEventCreate(&e));
-    float t[4] = {0.f, 0.f, 0.f, 0.f}; // [swizzle on: plain, windowed; swizzle off: plain, windowed]
+    float t[4] = {0.f, 0.f, 0.f, 0.f}; // [XCD map on: plain, windowed; off: plain, windowed]
     const int nsw = ctx->opt_xcd_swizzle ? 2 : 1;
     for (int rep = 0; rep < 2; ++rep) { // (the first round warms all up)
         SX_HIP(hipEventRecord(ev[0], ctx->stream));
         for (int k = 0; k < 2 * nsw; ++k) {
-            const int swz = (ctx->opt_xcd_swizzle && k < 2) ? 1 : 0;
-            if ((k & 1) == 0)
-                hipLaunchKernelGGL((k_price<4096, 0>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx,
-                                   A->csc_val, y, c, static_cast<const int8_t *>(nullptr), 1e-6, static_cast<double *>(nullptr), partial,
-                                   static_cast<const double *>(nullptr));
-            else
-                hipLaunchKernelGGL((k_price_lw<4, 0>), dim3(nb), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz, A->csc_win_lo, A->csc_ptr,
-                                   A->csc_idx, A->csc_val, A->m, y, c, static_cast<const int8_t *>(nullptr), 1e-6, static_cast<double *>(nullptr), partial);
+            SX_TRY(launch(k & 1, (ctx->opt_xcd_swizzle && k < 2) ? 1 : 0));
             SX_HIP(hipEventRecord(ev[k + 1], ctx->stream));
         }
         SX_HIP(hipEventSynchronize(ev[2 * nsw]));
@@ -655,7 +644,18 @@ SX_API int sx_score_columns_dev(sx_ctx *ctx, const sx_matrix *A, const double *y
     SX_REQUIRE(!code || (x && l && u), "code requested but x/l/u is NULL");
     if (A->n == 0) return SX_OK;
     int run = 0; // LDS operand window (sx_window.h): table built on first use; a large matrix is timed once, else the rule decides
-    SX_TRY(window_autotune(ctx, A, y, c));
+    SX_TRY(window_autotune(ctx, A, [&](int windowed, int swz) -> int {
+        if (windowed) {
+            const int64_t nruns = (A->n_csc_tiles + 3) / 4;
+            hipLaunchKernelGGL((k_score_columns_lw<4, 0>), dim3(walk_grid(ctx, nruns)), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz,
+                               A->csc_win_lo, A->csc_ptr, A->csc_idx, A->csc_val, A->m, y, c, x, l, u, gamma, s_d, code);
+        } else {
+            hipLaunchKernelGGL((k_score_columns<4096, 0>), dim3(walk_grid(ctx, A->n_csc_tiles)), dim3(SX_WG), 0, ctx->stream, A->csc_tiles,
+                               A->n_csc_tiles, swz, A->csc_ptr, A->csc_idx, A->csc_val, y, c, x, l, u, gamma, s_d, code,
+                               static_cast<const double *>(nullptr));
+        }
+        return SX_OK;
+    }));
     SX_TRY(sx_window_run_csc(ctx, A, &run));
     if (run) {
         const int swz = sx_csc_swizzle(ctx, A);
@@ -818,7 +818,19 @@ SX_API int sx_price_dev(sx_ctx *ctx, const sx_matrix *A, const double *y, const 
     SX_REQUIRE(A->csc_ptr != nullptr, "matrix has no CSC layout (row shard?)");
     SX_REQUIRE(y && c && result_dev, "y, c or result is NULL");
     // the swizzled walk needs a grid that is a multiple of 8 (one slice per XCD)
-    SX_TRY(window_autotune(ctx, A, y, c));
+    SX_TRY(window_autotune(ctx, A, [&](int windowed, int swz_) -> int {
+        int nb_ = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID) & ~7;
+        if (nb_ < 8) return SX_OK;
+        SX_TRY(sx_reserve(ctx, static_cast<size_t>(nb_) * sizeof(PricePartial)));
+        PricePartial *part_ = static_cast<PricePartial *>(ctx->ws);
+        if (windowed)
+            hipLaunchKernelGGL((k_price_lw<4, 0>), dim3(nb_), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz_, A->csc_win_lo, A->csc_ptr,
+                               A->csc_idx, A->csc_val, A->m, y, c, vbasis, tol, rc, part_);
+        else
+            hipLaunchKernelGGL((k_price<4096, 0>), dim3(nb_), dim3(SX_WG), 0, ctx->stream, A->csc_tiles, A->n_csc_tiles, swz_, A->csc_ptr, A->csc_idx,
+                               A->csc_val, y, c, vbasis, tol, rc, part_, static_cast<const double *>(nullptr));
+        return SX_OK;
+    }));
     const int swz = sx_csc_swizzle(ctx, A);
     int nb = static_cast<int>(A->n_csc_tiles < PRICE_GRID ? A->n_csc_tiles : PRICE_GRID);
     if (swz) nb &= ~7;

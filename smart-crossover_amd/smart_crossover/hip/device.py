@@ -41,6 +41,10 @@ class Context:
         self._timer_depth = 0
 
     # -- lifetime ---------------------------------------------------------
+    def prefetch_block(self, nbytes: int) -> None:
+        """Start allocating the context's big block (eta file + tableau of the sparse crossover) on a helper thread."""
+        _l.check(self._lib.sx_ctx_prefetch_block(self.handle, int(nbytes)))
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self._lib.sx_ctx_destroy(self.handle)

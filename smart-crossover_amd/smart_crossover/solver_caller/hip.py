@@ -201,12 +201,27 @@ class HipCaller(SolverCaller):
                 y0 = np.asarray(self._warm_point[1], dtype=np.float64)
                 y0 = np.where(self._row_lt.astype(bool), np.minimum(y0, 0.0), y0) if y0.size == m else np.zeros(m)
                 d_px, d_py = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+                if to_band and m >= 200_000:
+                    # the sparse crossover's eta file (<= 16 GB) + tableau: allocated while the first-order stage runs
+                    # (hipMalloc of 28 GB takes 0.5-1.4 s; sx_crossover_band_dev finds the block in the context)
+                    mp = 1.012 * m + 20000
+                    ctx.prefetch_block(int(min(16e9, 8.0 * mp * 20000) + 8.0 * mp * (0.0016 * m + 700)))
                 self.pdlp = ctx.pdlp(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), put(x0), put(y0), iters,
                                      float(os.environ.get("SX_PDLP_TOL", PDLP_TOL)), d_px, d_py)
                 self._warm_point = (d_px.download(), d_py.download())
                 self.pdlp_seconds = time.perf_counter() - t0
                 if to_band:      # ("dense": K16 whatever the size)
                     self._res = self._band(ctx, dA, d_b, d_c, d_l, d_u, d_px, None, None, d_x, d_y, d_vb, d_cb)
+                    full = int(os.environ.get("SX_PDLP_ITERS", PDLP_ITERS))
+                    if self._res is None and iters < full:
+                        # the sparse crossover does not take this LP (no band structure: config 2) and the dense one needs the
+                        # point the FULL first-order budget leaves (239,796 pivots behind 5,000 iterations, 692 behind 20,000):
+                        # the stage goes on from where it stopped
+                        self.pdlp = ctx.pdlp(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), put(self._warm_point[0]),
+                                             put(self._warm_point[1]), full - iters,
+                                             float(os.environ.get("SX_PDLP_TOL", PDLP_TOL)), d_px, d_py)
+                        self._warm_point = (d_px.download(), d_py.download())
+                        self.pdlp_seconds = time.perf_counter() - t0
             if self._res is None:
                 self._warm = self._crash_basis(ctx, dA)
             if self._warm is not None:          # crossover: start AT the interior point (superbasic columns)

@@ -166,3 +166,40 @@ def test_projector_cg_over_the_layout_matches_the_plain_walk(ctx):
     assert out[1][0] == pytest.approx(out[0][0], rel=1e-9)
     np.testing.assert_allclose(out[1][3], out[0][3], rtol=1e-6, atol=1e-9 * np.abs(out[0][3]).max())
     np.testing.assert_allclose(out[1][4], out[0][4], rtol=1e-6, atol=1e-9 * max(np.abs(out[0][4]).max(), 1e-300))
+
+
+def test_long_row_super_tiles_dealt_over_the_xcds_change_nothing_but_the_order_of_work(ctx):
+    """Option rb_long_xcd (sx_rowblock.hip rb_build_order): a netlib-style LP with all its linking rows at the head puts every
+    long-row super-tile on XCD 0 under the XCD-contiguous map; dealt over the eight XCDs (1: always, -1: the automatic rule,
+    which fires here) the walk visits the same super-tiles in another order -- s_p and the flags are the plain walk's, bit
+    for bit -- and the CG's row pass over the same map ends on the same projector norm."""
+    inst = workloads.netlib_lp(70_000, 700_000, seed=2)
+    A, x, b, y = inst.A, inst.x, inst.b, inst.y
+    m, n = A.shape
+    ctx.set_option("rowblock", 0)
+    dA = ctx.matrix(A)
+    want = k2(ctx, dA, x, b, y)
+    dA.free()
+    ctx.set_option("rowblock", 1)
+    try:
+        for mode in (0, 1, -1):
+            ctx.set_option("rb_long_xcd", mode)
+            dB = ctx.matrix(A)
+            got = k2(ctx, dB, x, b, y)
+            assert dB.rowblock() is not None and dB.rowblock()["nst"] >= 64
+            assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)) and np.array_equal(got[1], want[1]), mode
+            dB.free()
+        rng = np.random.default_rng(5)
+        xa, xs, c = rng.uniform(0.1, 1, n), rng.uniform(0.1, 1, m), rng.standard_normal(n)
+        norms = {}
+        for mode in (0, 1):
+            ctx.set_option("rb_long_xcd", mode)
+            dB = ctx.matrix(A)
+            pc, pr = ctx.empty(n, np.float64), ctx.empty(m, np.float64)
+            res = ctx.projector_norm(dB, ctx.to_device(xa), ctx.to_device(xs), ctx.to_device(c), 1e-10, 300, pc, pr)
+            norms[mode] = (res.proj_norm, int(res.iters))
+            dB.free()
+        assert norms[0][1] == norms[1][1] and norms[1][0] == pytest.approx(norms[0][0], rel=1e-12)
+    finally:
+        ctx.set_option("rb_long_xcd", -1)
+        ctx.set_option("rowblock", -1)
