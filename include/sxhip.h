@@ -521,6 +521,10 @@ int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
                           const double *u, const uint8_t *row_is_lt, const double *x_start, int64_t max_iter,
                           double feas_tol, double opt_tol, double *x, double *y, int8_t *vbasis, int8_t *cbasis,
                           sx_simplex_result *result);
+/* sx_crossover_band_probe_dev: would the sparse crossover take this LP from this point?  Its set-up up to the band-width
+ * check only (host copies, row order, guessed basic set, matching): SX_OK or SX_ERR_UNSUPPORTED, nothing is solved. */
+int sx_crossover_band_probe_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                const double *u, const uint8_t *row_is_lt, const double *x_start);
 int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
                                 const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
                                 const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x,

@@ -414,6 +414,10 @@ __host__ __device__ inline size_t gb_lds_bytes(int R) {
 // the panel's own 32 x 32 block of the factors (L strictly below the diagonal, U on and above) -> blk[r][c]
 __device__ __forceinline__ void gb_load_block(const double *__restrict__ ab, int ldab, int kl, int ku, int64_t j0, int ncol,
                                               double *blk) {
+    // (the padding slot of every row is written too: for a panel of fewer than 32 columns -- the matrix' last -- gb_combine
+    //  multiplies 32 rows of x, i.e. up to 248 doubles of THIS block behind the panel's own rows of w, by factor entries that
+    //  are zero there; a never-written slot held a NaN now and then: test_solves_match_lapack[50-3-2-0] failed once in ~10 runs)
+    if (threadIdx.x < GB_NB) blk[threadIdx.x * (GB_NB + 1) + GB_NB] = 0.0;
     for (int e = threadIdx.x; e < GB_NB * GB_NB; e += GB_T2) {
         const int r = e / GB_NB, c = e % GB_NB;
         double v = 0.0;

@@ -1029,10 +1029,11 @@ void rows_from_triplets(int64_t nrows, const std::vector<int32_t> &row, const st
 // One entry for the three ways the sparse crossover is started: from the first-order point alone (vbasis_in == NULL: the
 // basis is guessed from the margins), or from a given basis (the reference's warm-started final solve,
 // lp_methods/algorithms.py:69-74; sx_crossover_band_dev passes NULL).
-SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
-                                       const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
-                                       const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
-                                       double *y_out, int8_t *vbasis_out, int8_t *cbasis_out, sx_simplex_result *result) {
+namespace {
+int crossover_band_impl(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                        const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
+                        const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
+                        double *y_out, int8_t *vbasis_out, int8_t *cbasis_out, sx_simplex_result *result, bool probe_only) {
     SX_ENTER(ctx);
     SX_REQUIRE(A && b && c && l && u && x_start && result, "NULL argument");
     SX_REQUIRE((vbasis_in == nullptr) == (cbasis_in == nullptr), "vbasis_in and cbasis_in come together");
@@ -1470,6 +1471,10 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
             return SX_ERR_UNSUPPORTED;
         }
         if (trace) fprintf(stderr, "[sx_crossover_band] epoch %d: matching and band assembly done at %.1f ms\n", epochs, now() - t_begin);
+        if (probe_only) { // (sx_crossover_band_probe_dev: the matched basis is a band the LU takes -- that was the question)
+            result->status = 0;
+            return SX_OK;
+        }
         // ---------------------------------------------------------------- factor B11
         sx_bandlu *lu = nullptr;
         sx_denselu *dl = nullptr;
@@ -2259,6 +2264,25 @@ SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const do
                         "pricing, objective %.12e, max violation %.2e, largest blocks %.2f GB, %.1f ms\n", (long long)result->status, tot_iters, tot_pivots, tot_flips,
                 tot_degen, epochs, (long long)added_total, obj, result->max_violation, static_cast<double>(peak_bytes) * 1e-9, now() - t_begin);
     return SX_OK;
+}
+
+} // namespace
+
+SX_API int sx_crossover_band_basis_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                       const double *u, const uint8_t *row_is_lt, const double *x_start, const int8_t *vbasis_in,
+                                       const int8_t *cbasis_in, int64_t max_iter, double feas_tol, double opt_tol, double *x_out,
+                                       double *y_out, int8_t *vbasis_out, int8_t *cbasis_out, sx_simplex_result *result) {
+    return crossover_band_impl(ctx, A, b, c, l, u, row_is_lt, x_start, vbasis_in, cbasis_in, max_iter, feas_tol, opt_tol, x_out, y_out, vbasis_out,
+                               cbasis_out, result, false);
+}
+
+// Would the sparse crossover take this LP from this point?  Runs its set-up up to the band-width check -- host copies, row
+// order, the basic set guessed from x_start, matching -- and nothing else: SX_OK / SX_ERR_UNSUPPORTED.  A backend asks before
+// it sizes its first-order stage (the dense crossover needs four times the iterations in front of it).
+SX_API int sx_crossover_band_probe_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,
+                                       const double *u, const uint8_t *row_is_lt, const double *x_start) {
+    sx_simplex_result r{};
+    return crossover_band_impl(ctx, A, b, c, l, u, row_is_lt, x_start, nullptr, nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr, &r, true);
 }
 
 SX_API int sx_crossover_band_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const double *c, const double *l,

@@ -203,6 +203,9 @@ SX_API int sx_ctx_set_option(sx_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "rb_long_xcd")) {
         SX_REQUIRE(value >= -1 && value <= 1, "rb_long_xcd must be -1 (auto), 0 (never) or 1 (always)");
         ctx->opt_rb_long_xcd = static_cast<int>(value);
+    } else if (!strcmp(key, "rb_dense_min")) {
+        SX_REQUIRE(value >= 1, "rb_dense_min must be positive");
+        ctx->opt_rb_dense_min = static_cast<int>(value > (1 << 30) ? (1 << 30) : value); // (read when a layout is built)
     } else if (!strcmp(key, "rb_long_rows")) {
         SX_REQUIRE(value >= 1 && value <= 64, "rb_long_rows must be in [1, 64]");
         ctx->opt_rb_long_rows = static_cast<int>(value); // (read when a layout is built)

@@ -109,6 +109,8 @@ struct sx_ctx {
     int opt_run_prefetch = 0;  // windowed column walk (K1, K10): loads one step ahead (sx_runwalk.h); 0: tile by tile
     int opt_rb_long_xcd = -1;  // row-blocked walks: the long-row super-tiles dealt over the XCDs (sx_rowblock.h: order[]): -1 when the
                                // matrix puts them unevenly, 0 never, 1 always
+    int opt_rb_dense_min = 512; // entries from which a column block of a super-tile gets an LDS window (read when a layout is built;
+                                // sx_rowblock.h RB_DENSE_MIN)
     int opt_rb_long_rows = 64; // rows per super-tile of long rows (read when a layout is built; sx_rowblock.h RB_LONG_ROWS)
     int opt_rb_stage_long = 0; // row-blocked layout: products of the long rows by a column-ordered pre-pass (0: gather in the
                                // walk).  Measured SLOWER (K2 0.442 vs 0.381 ms at config 5: the 1e7 scattered 8-byte stores cost more

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(SX_WG) void k_rb_bins(const int64_t *__restrict__ t
 // ---------------------------------------------------------------- bins -> cells (one lane per super-tile)
 // pass 0: loc[bin] = cell number inside the super-tile, ncell[st] = cells of the super-tile
 // pass 1: cellid[bin] = global cell number; cell_ne / cell_col0 / cell_pad / cell_nch per cell
-__global__ __launch_bounds__(SX_WG) void k_rb_cells(int pass, int64_t nst, int64_t nblk,
+__global__ __launch_bounds__(SX_WG) void k_rb_cells(int pass, int dense_min, int64_t nst, int64_t nblk,
                                                     const int32_t *__restrict__ cnt,
                                                     const int32_t *__restrict__ slice,
                                                     const int64_t *__restrict__ cell_base,
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SX_WG) void k_rb_cells(int pass, int64_t nst, int64
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t c = cnt[st * nblk + b];
         if (c == 0) continue;
-        const bool dense = c >= RB_DENSE_MIN && !is_long;
+        const bool dense = c >= dense_min && !is_long;
         const bool alone = dense || is_long;
         if (started && !alone && !prev_alone && run + c <= RB_MERGE_MAX) {
             run += c;
@@ -352,7 +352,7 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
 
     hipLaunchKernelGGL(k_rb_bins, dim3(static_cast<unsigned>(A->n_csr_tiles)), dim3(SX_WG), 0, s, A->csr_tiles,
                        A->n_csr_tiles, A->csr_ptr, A->csr_idx, d_cuts, nst, d_slice, nblk, d_cnt, d_ebin, d_elrow, d_desc);
-    hipLaunchKernelGGL(k_rb_cells, dim3(grid1d(nst)), dim3(SX_WG), 0, s, 0, nst, nblk, d_cnt, d_slice,
+    hipLaunchKernelGGL(k_rb_cells, dim3(grid1d(nst)), dim3(SX_WG), 0, s, 0, ctx->opt_rb_dense_min, nst, nblk, d_cnt, d_slice,
                        static_cast<const int64_t *>(nullptr), d_loc, d_ncell, static_cast<int64_t *>(nullptr),
                        static_cast<int32_t *>(nullptr), static_cast<int64_t *>(nullptr), static_cast<int64_t *>(nullptr),
                        d_totals);
@@ -373,7 +373,7 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
     SX_TRY(tmp.get(static_cast<size_t>(ncells) + 1, &d_cell_first, false, s));
     SX_TRY(tmp.get(static_cast<size_t>(ncells) + 1, &d_ch_first, false, s));
     SX_TRY(tmp.get(static_cast<size_t>(ncells), &d_cell_col0, false, s));
-    hipLaunchKernelGGL(k_rb_cells, dim3(grid1d(nst)), dim3(SX_WG), 0, s, 1, nst, nblk, d_cnt, d_slice, d_cell_base, d_loc,
+    hipLaunchKernelGGL(k_rb_cells, dim3(grid1d(nst)), dim3(SX_WG), 0, s, 1, ctx->opt_rb_dense_min, nst, nblk, d_cnt, d_slice, d_cell_base, d_loc,
                        d_ncell, d_cell_ne, d_cell_col0, d_cell_pad, d_cell_nch, d_totals);
     SX_TRY(sx_scan_exclusive(ctx, d_cell_pad, ncells, d_cell_e0));
     SX_TRY(sx_scan_exclusive(ctx, d_cell_ne, ncells, d_cell_first));

@@ -285,6 +285,14 @@ class Context:
                                                        float(opt_tol), _ptr(x), _ptr(y), _ptr(vbasis_out), _ptr(cbasis_out), C.byref(res)))
         return res
 
+    def crossover_band_takes(self, A, b, c, l, u, row_is_lt, x_start) -> bool:
+        """K16s' set-up up to its band-width check: would ``crossover_band`` take this LP from this point?"""
+        rc = self._lib.sx_crossover_band_probe_dev(self.handle, A.handle, _ptr(b), _ptr(c), _ptr(l), _ptr(u), _ptr(row_is_lt), _ptr(x_start))
+        if rc == _l.SX_ERR_UNSUPPORTED:
+            return False
+        _l.check(rc)
+        return True
+
     def net_simplex(self, A, b, c, l, u, vbasis, cbasis, max_iter=0, feas_tol=1e-7, opt_tol=1e-7, x=None, y=None,
                     vbasis_out=None, cbasis_out=None) -> "_l.SimplexResult":
         """K16n (blocking): primal network simplex from a spanning-tree basis; status 5 = the problem or the

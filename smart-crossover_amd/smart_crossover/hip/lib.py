@@ -136,6 +136,7 @@ PROTOTYPES = {
                                      C.POINTER(SimplexResult)]),
     "sx_crossover_band_basis_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                            C.POINTER(SimplexResult)]),
+    "sx_crossover_band_probe_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sx_bandlu_create_dev": (_int, [_vp, _i64, _int, _int, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "sx_bandlu_factor_dev": (_int, [_vp, _dbl, C.POINTER(_i64), _vp, _vp]),
     "sx_bandlu_factor_blocks_dev": (_int, [_vp, _dbl, _int, _i64, _i64, _i64, C.POINTER(_i64), _vp, _vp]),

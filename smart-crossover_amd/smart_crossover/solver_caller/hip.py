@@ -193,6 +193,13 @@ class HipCaller(SolverCaller):
         if self._warm is None and getattr(self, "_want_crash", False):
             mode = os.environ.get("SX_LP_CROSSOVER", "auto")
             to_band = mode == "band" or (mode == "auto" and m >= BAND_MIN_ROWS)
+            if (to_band and mode == "auto" and m < 200_000 and self._warm_point is not None
+                    and np.asarray(self._warm_point[0]).size == n):
+                # the dense crossover needs the full first-order budget in front of it: ask the sparse one now whether it
+                # will take this LP (its matching on the point at hand: ~20 ms at 1e5 rows; at 1e6 rows the question costs
+                # 0.2 s and is not asked -- a refusal there lets the first-order stage go on to the full budget instead)
+                x_probe = put(np.clip(np.asarray(self._warm_point[0], dtype=np.float64), self._l, self._u))
+                to_band = ctx.crossover_band_takes(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), x_probe)
             iters = int(os.environ.get("SX_PDLP_ITERS", _pdlp_iterations(m, to_band)))
             if self._warm_point is not None and iters > 0 and np.asarray(self._warm_point[0]).size == n:
                 # what the reference's backends do with 'barrier' before their crossover: carry the interior point

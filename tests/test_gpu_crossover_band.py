@@ -482,3 +482,28 @@ def test_hostile_structure_reaches_highs_optimum_on_one_path_or_the_other(ctx, m
     ref = linprog(sub.c, A_ub=sub.A[lt], b_ub=sub.b[lt], A_eq=sub.A[~lt], b_eq=sub.b[~lt], bounds=np.c_[sub.l, sub.u], method="highs")
     assert ref.status == 0
     assert float(sub.c @ out.x) == pytest.approx(ref.fun, rel=1e-7, abs=1e-8)
+
+
+def test_probe_answers_before_the_first_order_stage_is_sized(ctx, monkeypatch):
+    """sx_crossover_band_probe_dev: the sparse crossover's set-up up to its band-width check.  A staircase LP is taken, an
+    unstructured one is not -- and the backend that asked sizes the first-order stage for the crossover that will run: the
+    full 20,000 iterations in front of the dense one (config 2's shape: 239,796 pivots behind 5,000 iterations, 692 behind
+    20,000), m / 20 (at least 5,000) in front of the sparse one."""
+    put = lambda v, t=np.float64: ctx.to_device(np.ascontiguousarray(v, dtype=t))   # noqa: E731
+    takes = {}
+    for name, inst in (("staircase", workloads.netlib_lp(3000, 30000, seed=2)),
+                       ("unstructured", workloads.sparse_lp(2000, 8000, 6, seed=9, stratified=True))):
+        lp, mgr = perturbed_sub_problem(inst)
+        sub = mgr.lp_sub
+        dA = ctx.matrix(sub.A)
+        takes[name] = ctx.crossover_band_takes(dA, put(sub.b), put(sub.c), put(sub.l), put(sub.u), put(np.asarray(sub.sense) == "<", np.uint8),
+                                               put(np.clip(mgr.get_subx(inst.x), sub.l, sub.u)))
+        dA.free()
+        caller, out = resolve(mgr, inst, monkeypatch, "auto")
+        assert out.status == "OPTIMAL"
+        certificates(sub, out)
+        assert caller.solved_by == ("crossover_band" if takes[name] else "simplex")
+        assert int(caller.pdlp.iters) <= (5056 if takes[name] else 20032)
+        if not takes[name]:
+            assert int(caller.pdlp.iters) > 5056 or int(caller.pdlp.status) == 0      # (the full budget, unless it converged before)
+    assert takes == {"staircase": True, "unstructured": False}

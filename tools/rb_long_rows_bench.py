@@ -20,6 +20,7 @@ from smart_crossover.hip import Context  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="shard")
+    ap.add_argument("--option", default="rb_long_rows", help="layout option the positional values are for (rb_long_rows | rb_dense_min)")
     ap.add_argument("heights", nargs="*", type=int, default=[64, 32, 16, 8])
     args = ap.parse_args()
     if args.workload == "shard":
@@ -41,13 +42,13 @@ def main():
     ctx.set_option("rowblock", 1)
     mats = {}
     for h in args.heights:
-        ctx.set_option("rb_long_rows", h)
+        ctx.set_option(args.option, h)
         mats[h] = ctx.row_shard(A)
         s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
         ctx.score_rows(mats[h], d_x, d_b, d_y, 1e-3, s_p, flag)     # builds the layout
         ctx.sync()
         same = bool(np.array_equal(s_p.download().view(np.uint64), want[0]) and np.array_equal(flag.download(), want[1]))
-        print(f"rb_long_rows={h}: layout {mats[h].rowblock()}, bit-identical to the plain walk {same}", flush=True)
+        print(f"{args.option}={h}: layout {mats[h].rowblock()}, bit-identical to the plain walk {same}", flush=True)
     times = {h: [] for h in args.heights}
     s_p, flag = ctx.empty(m, np.float64), ctx.empty(m, np.uint8)
     for _ in range(5):
@@ -60,7 +61,7 @@ def main():
             times[h].append(ctx.marker_elapsed(0, 1) / 10)
     for h in args.heights:
         t = np.array(times[h])
-        print(f"K2 rb_long_rows={h:3d}: {np.median(t):.4f} ms (min {t.min():.4f}) = {k2_bytes / np.median(t) / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+        print(f"K2 {args.option}={h:6d}: {np.median(t):.4f} ms (min {t.min():.4f}) = {k2_bytes / np.median(t) / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
 
 
 if __name__ == "__main__":
