@@ -130,6 +130,23 @@ def test_headline_size_1e6_variables(ctx, monkeypatch):
         assert alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x)) is True
 
 
+def test_config5_size_1e6_rows(ctx, monkeypatch):
+    """BASELINE configs[4]'s size: netlib_lp(1e6, 1e7), 8e7 entries -- interior point to optimal vertex + basis of the
+    perturbed 1e6 x 1e6 sub-problem on the GPU (first-order stage + sparse crossover on the bordered factorisation: band in
+    32 blocks, Schur complement of ~13,800 rows), with the certificates of the headline test and the reference's gap test.
+    (Sparse matrix products on the host check a 1e6-row vertex in seconds; HiGHS has no answer at this size.)"""
+    from smart_crossover.lp_methods import algorithms as alg
+    inst = workloads.netlib_lp(1_000_000, 10_000_000)
+    lp, mgr = perturbed_sub_problem(inst)
+    assert mgr.lp_sub.A.shape[0] == 1_000_000
+    caller, out = resolve(mgr, inst, monkeypatch, "auto")
+    assert caller.solved_by == "crossover_band" and out.status == "OPTIMAL"
+    assert int(out.iter_count) < 5000          # (round 3: 8,273 -- one per linking row -- on a 66-99 GB tableau)
+    certificates(mgr.lp_sub, out)
+    with redirect_stdout(io.StringIO()):
+        assert alg.check_perturb_output_precision(mgr, out.x, lp.c, float(lp.c @ inst.x)) is True
+
+
 def small_band_lp(m=400, n=1600, seed=11):
     """A well-conditioned staircase LP in computational form for direct calls of the sparse crossover."""
     inst = workloads.netlib_lp(m, n, seed=seed)
