@@ -192,8 +192,18 @@ def _cpu_path_record(name: str, which: dict, limit_s: float, objective: float, g
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import cpu_lp_path                      # (imports oracle/: checker / baseline only)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        rec = cpu_lp_path.run(dict(which, limit=limit_s, out=os.path.join(ROOT, "gpurun_out", name)))
+        # the CPU path gets the host's whole CPU quota for its BLAS / OpenMP pools (the device path cuts them to a quarter
+        # for the sake of its launching thread: smart_crossover/hip/host_threads.py)
+        from smart_crossover.hip import host_threads
+        quota = host_threads.cpu_quota()
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=quota):
+                rec = cpu_lp_path.run(dict(which, limit=limit_s, out=os.path.join(ROOT, "gpurun_out", name)))
+        except ImportError:
+            rec = cpu_lp_path.run(dict(which, limit=limit_s, out=os.path.join(ROOT, "gpurun_out", name)))
         rec["measured"] = "in this run, on this host"
+        rec["host_cpu_quota"] = quota
     else:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
@@ -233,11 +243,10 @@ def _device_lp_crossover(inst, reps: int, what: str):
     for rep in range(reps):
         lp = GeneralLP(inst.A, inst.b.copy(), inst.c.copy(), inst.l.copy(), inst.u.copy(), inst.sense.copy())
         if rep == reps - 1 and reps >= 3 and "back_to_back" not in os.environ.get("SX_BENCH_EXPERIMENT", ""):
-            # the LAST call is timed after what the call before it left behind has drained: for ~0.2 s after a crossover returns
-            # the device is still busy on its behalf (1.3 GB of factors, sweeps' responses and matrices were just freed), and a
-            # call that starts inside that window has the launches of its projector CG delayed by ~90 ms -- round 3's
-            # "in-bench slowdown" (profiles/r04/in_bench_slowdown.md).  The call before it (index reps - 2) starts right behind
-            # its predecessor and is reported as the back-to-back figure.
+            # the LAST call is timed after a pause, the call before it (index reps - 2) right behind its predecessor: the
+            # back-to-back figure.  They differed by ~90 ms (round 3's "in-bench slowdown") until the host's BLAS / OpenMP
+            # pools were cut to the CPU quota (smart_crossover/hip/host_threads.py; profiles/r04/in_bench_slowdown.md);
+            # both stay in the line.
             time.sleep(0.25)
         t0 = time.perf_counter()
         with redirect_stdout(io.StringIO()):
@@ -264,7 +273,7 @@ def _device_lp_crossover(inst, reps: int, what: str):
             "sub_problem_shape": list(mgr.lp_sub.A.shape), "gpu_ms": tot * 1e3, "gpu_ms_first_call": runs[0][0] * 1e3,
             "gpu_ms_calls": [r[0] * 1e3 for r in runs],
             "gpu_ms_back_to_back": runs[-2][0] * 1e3 if len(runs) >= 3 else None,
-            "timing_note": "gpu_ms = the last call, started 0.25 s after the call before it returned (its teardown drained); "
+            "timing_note": "gpu_ms = the last call, started 0.25 s after the call before it returned; "
                            "gpu_ms_back_to_back = the call before, started right behind its predecessor; gpu_ms_first_call also pays "
                            "the first-use set-up of kernels and layouts" if len(runs) >= 3 else "one call",
             "gpu_get_perturb_problem_ms": tgp * 1e3, "gpu_resolve_ms": trs * 1e3,
@@ -951,6 +960,11 @@ def main():
         if os.environ.get("SX_BENCH_ONLY_LP_1E6"):     # profiling aid (tools/gpu/prof_inbench.sh): the headline leg alone, in bench.py's process state
             rec = _device_lp_crossover(workloads.netlib_lp(), 3, "netlib_lp (the 1e6-variable LP of the metric)")
             print(json.dumps({"lp_1e6_end_to_end": rec}), flush=True)
+            return
+        if os.environ.get("SX_BENCH_ONLY_LP_C5"):      # ... the config-5-size leg alone, N calls
+            rec = _device_lp_crossover(workloads.netlib_lp(1_000_000, 10_000_000), int(os.environ["SX_BENCH_ONLY_LP_C5"]),
+                                       "netlib_lp(1e6, 1e7) = config-5 size")
+            print(json.dumps({"lp_c5_end_to_end": rec}), flush=True)
             return
         net_c3, net_mcf = crossover_network(), crossover_mcf()
         net_c4 = crossover_mcf(2 ** 17, 2 ** 20, solvers=("HIP", "HGS") if args.c4_highs else ("HIP",), repeats=1)

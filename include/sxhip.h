@@ -122,6 +122,14 @@ int sx_ctx_sync_device(sx_ctx *ctx);
  * a block of that size already held or on its way: nothing happens; bytes = 0 frees what the context holds; a request
  * beyond 60 % of the free memory is ignored (the call then allocates what it can by itself). */
 int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes);
+/* Device memory pool of the library (process-wide, per device): the library's own allocations -- matrices, factors, work
+ * blocks -- are kept when freed and handed to the next request of their size class, so that a pipeline of crossovers
+ * (the reference calls run_perturb_algorithm once per LP, lp_methods/algorithms.py:42-74) neither pays hipMalloc again nor
+ * runs into the driver's clean-up of what the previous call freed.  At most 16 GiB are kept per device (SX_POOL_MAX, bytes),
+ * blocks above 8 GiB are not (SX_POOL_BLOCK_MAX); SX_POOL=0 turns the pool off.  sx_pool_trim hands everything kept back
+ * to the driver; sx_pool_stats reports bytes kept / bytes in use and requests served by the pool / by the driver. */
+int sx_pool_trim(void);
+int sx_pool_stats(uint64_t *cached_bytes, uint64_t *live_bytes, uint64_t *hits, uint64_t *misses);
 
 /* ------------------------------------------------------------------ matrix */
 /* Upload an m x n matrix.  Host CSR arrays are required (the reference keeps A as scipy CSR,

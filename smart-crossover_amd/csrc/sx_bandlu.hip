@@ -1122,18 +1122,18 @@ SX_API int sx_bandlu_create_dev(sx_ctx *ctx, int64_t n, int kl, int ku, int64_t 
         sx_bandlu *h;
         ~Guard() {
             if (h) {
-                (void)hipFree(h->ab);
-                (void)hipFree(h->ipiv);
-                (void)hipFree(h->d_swaps);
-                (void)hipFree(h->d_flags);
+                (void)sx_dfree(h->ab);
+                (void)sx_dfree(h->ipiv);
+                (void)sx_dfree(h->d_swaps);
+                (void)sx_dfree(h->d_flags);
                 delete h;
             }
         }
     } guard{h};
     const size_t bytes = sizeof(double) * static_cast<size_t>(h->ldab) * static_cast<size_t>(n);
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ab), bytes));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4)));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_swaps), static_cast<size_t>((n + GB_NB - 1) / GB_NB) + 8));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->ab), bytes));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * (2 * static_cast<size_t>(n) + 4)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->d_swaps), static_cast<size_t>((n + GB_NB - 1) / GB_NB) + 8));
     h->replaced = h->ipiv + n;
     h->err = h->replaced + n;
     hipStream_t s = ctx->stream;
@@ -1164,13 +1164,13 @@ SX_API int sx_bandlu_destroy(sx_bandlu *h) {
     if (!h) return SX_OK;
     sx_device_guard guard(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    (void)hipFree(h->ab);
-    (void)hipFree(h->ipiv);
-    (void)hipFree(h->d_swaps);
-    (void)hipFree(h->d_flags);
-    for (double *r : h->part_R) (void)hipFree(r);
-    (void)hipFree(h->part_buf);
-    (void)hipFree(h->part_delta);
+    (void)sx_dfree(h->ab);
+    (void)sx_dfree(h->ipiv);
+    (void)sx_dfree(h->d_swaps);
+    (void)sx_dfree(h->d_flags);
+    for (double *r : h->part_R) (void)sx_dfree(r);
+    (void)sx_dfree(h->part_buf);
+    (void)sx_dfree(h->part_delta);
     delete h;
     return SX_OK;
 }
@@ -1291,12 +1291,12 @@ int gb_part_prepare(sx_bandlu *h) {
     hipStream_t s = h->ctx->stream;
     for (int kind = 0; kind < 4; ++kind) {
         const GbPart D = gb_part_desc(h, kind);
-        if (hipMalloc(&h->part_R[kind], sizeof(double) * D.rows_total() * D.w) != hipSuccess) return SX_OK;
+        if (sx_dmalloc(&h->part_R[kind], sizeof(double) * D.rows_total() * D.w) != hipSuccess) return SX_OK;
         hipLaunchKernelGGL(k_gbp_unit, dim3(64, static_cast<unsigned>(D.P)), dim3(256), 0, s, D, h->part_R[kind]);
         gb_part_launch_sweep(h, D, D.w, h->part_R[kind]);
     }
-    if (hipMalloc(&h->part_buf, sizeof(double) * DU.rows_total() * GB_CB) != hipSuccess) return SX_OK;
-    if (hipMalloc(&h->part_delta, sizeof(double) * static_cast<size_t>(DU.P) * GB_CB * DU.w) != hipSuccess) return SX_OK;
+    if (sx_dmalloc(&h->part_buf, sizeof(double) * DU.rows_total() * GB_CB) != hipSuccess) return SX_OK;
+    if (sx_dmalloc(&h->part_delta, sizeof(double) * static_cast<size_t>(DU.P) * GB_CB * DU.w) != hipSuccess) return SX_OK;
     SX_HIP(hipGetLastError());
     h->part_cols = GB_CB;
     h->part_state = 1;
@@ -1313,13 +1313,13 @@ void gb_part_reserve(sx_bandlu *h, int ncols) {
     if (static_cast<double>(need) > 0.25 * static_cast<double>(free_b)) return;
     (void)hipStreamSynchronize(h->ctx->stream);
     double *buf = nullptr, *delta = nullptr;
-    if (hipMalloc(&buf, sizeof(double) * DU.rows_total() * static_cast<size_t>(ncols)) != hipSuccess) return;
-    if (hipMalloc(&delta, sizeof(double) * static_cast<size_t>(DU.P) * static_cast<size_t>(ncols) * DU.w) != hipSuccess) {
-        (void)hipFree(buf);
+    if (sx_dmalloc(&buf, sizeof(double) * DU.rows_total() * static_cast<size_t>(ncols)) != hipSuccess) return;
+    if (sx_dmalloc(&delta, sizeof(double) * static_cast<size_t>(DU.P) * static_cast<size_t>(ncols) * DU.w) != hipSuccess) {
+        (void)sx_dfree(buf);
         return;
     }
-    (void)hipFree(h->part_buf);
-    (void)hipFree(h->part_delta);
+    (void)sx_dfree(h->part_buf);
+    (void)sx_dfree(h->part_delta);
     h->part_buf = buf;
     h->part_delta = delta;
     h->part_cols = ncols;
@@ -1402,10 +1402,10 @@ SX_API int sx_bandlu_solve_sparse_dev(sx_bandlu *h, int64_t nrhs, double *X, int
     const size_t need = static_cast<size_t>(groups) * static_cast<size_t>(npanel);
     if (need > h->flags_cap) {
         SX_HIP(hipStreamSynchronize(s));
-        (void)hipFree(h->d_flags);
+        (void)sx_dfree(h->d_flags);
         h->d_flags = nullptr;
         h->flags_cap = 0;
-        SX_HIP(hipMalloc(&h->d_flags, need));
+        SX_HIP(sx_dmalloc(&h->d_flags, need));
         h->flags_cap = need;
     }
     SX_HIP(hipMemsetAsync(h->d_flags, 0, need, s));

@@ -203,7 +203,7 @@ inline unsigned bd_grid(int64_t n) { return static_cast<unsigned>(n > 0 ? (n + B
 } // namespace
 
 SxBorderOps::~SxBorderOps() {
-    for (void *q : {(void *)win_lo, (void *)v_val, (void *)d_v_lo, (void *)d_v_off, (void *)d_vb_ptr, (void *)d_vb_col}) (void)hipFree(q);
+    for (void *q : {(void *)win_lo, (void *)v_val, (void *)d_v_lo, (void *)d_v_off, (void *)d_vb_ptr, (void *)d_vb_col}) (void)sx_dfree(q);
 }
 
 int SxBorderOps::ftran(double *W, int64_t ncols, bool sparse_rhs, bool upto_schur) {
@@ -218,10 +218,10 @@ int SxBorderOps::ftran(double *W, int64_t ncols, bool sparse_rhs, bool upto_schu
     if (windows) {
         if (ncols > win_cap) {
             SX_HIP(hipStreamSynchronize(s));
-            (void)hipFree(win_lo);
+            (void)sx_dfree(win_lo);
             win_lo = win_hi = nullptr;
             win_cap = 0;
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&win_lo), sizeof(int32_t) * 2 * static_cast<size_t>(ncols)));
+            SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&win_lo), sizeof(int32_t) * 2 * static_cast<size_t>(ncols)));
             win_hi = win_lo + ncols;
             win_cap = ncols;
         }
@@ -293,22 +293,22 @@ int SxBorderOps::pack_v(const double *W, int64_t ncols, const int32_t *dest) {
             return SX_OK;
         }
         double *nv = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&nv), sizeof(double) * want) != hipSuccess) {
+        if (sx_dmalloc(reinterpret_cast<void **>(&nv), sizeof(double) * want) != hipSuccess) {
             v_failed = 1;
             return SX_OK;
         }
         if (v_used) SX_HIP(hipMemcpyAsync(nv, v_val, sizeof(double) * v_used, hipMemcpyDeviceToDevice, s));
         SX_HIP(hipStreamSynchronize(s));
-        (void)hipFree(v_val);
+        (void)sx_dfree(v_val);
         v_val = nv;
         v_cap = want;
     }
     int64_t *d_off = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d_off), sizeof(int64_t) * static_cast<size_t>(ncols)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d_off), sizeof(int64_t) * static_cast<size_t>(ncols)));
     SX_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * static_cast<size_t>(ncols), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_bd_pack, dim3(static_cast<unsigned>(ncols)), dim3(BD_WG), 0, s, W, mp, win_lo, win_hi, d_off, v_val);
     SX_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d_off);
+    (void)sx_dfree(d_off);
     v_used = need;
     return SX_OK;
 }
@@ -330,14 +330,14 @@ int SxBorderOps::finish_v(const std::vector<int32_t> &zero) {
     for (int64_t j = 0; j < nb; ++j) // (ascending j within a block: the order of the additions)
         if (v_hi[j] > v_lo[j])
             for (int64_t bk = v_lo[j] / BD_WG; bk <= (v_hi[j] - 1) / BD_WG; ++bk) col[at[bk]++] = static_cast<int32_t>(j);
-    for (void *q : {(void *)d_v_lo, (void *)d_v_off, (void *)d_vb_ptr, (void *)d_vb_col}) (void)hipFree(q);
+    for (void *q : {(void *)d_v_lo, (void *)d_v_off, (void *)d_vb_ptr, (void *)d_vb_col}) (void)sx_dfree(q);
     d_v_lo = d_v_hi = d_vb_col = nullptr;
     d_v_off = d_vb_ptr = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d_v_lo), sizeof(int32_t) * 2 * static_cast<size_t>(nb)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d_v_lo), sizeof(int32_t) * 2 * static_cast<size_t>(nb)));
     d_v_hi = d_v_lo + nb;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d_v_off), sizeof(int64_t) * static_cast<size_t>(nb)));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d_vb_ptr), sizeof(int64_t) * ptr.size()));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d_vb_col), sizeof(int32_t) * std::max<size_t>(col.size(), 1)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d_v_off), sizeof(int64_t) * static_cast<size_t>(nb)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d_vb_ptr), sizeof(int64_t) * ptr.size()));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d_vb_col), sizeof(int32_t) * std::max<size_t>(col.size(), 1)));
     SX_HIP(hipMemcpyAsync(d_v_lo, v_lo.data(), sizeof(int32_t) * static_cast<size_t>(nb), hipMemcpyHostToDevice, s));
     SX_HIP(hipMemcpyAsync(d_v_hi, v_hi.data(), sizeof(int32_t) * static_cast<size_t>(nb), hipMemcpyHostToDevice, s));
     SX_HIP(hipMemcpyAsync(d_v_off, v_off.data(), sizeof(int64_t) * static_cast<size_t>(nb), hipMemcpyHostToDevice, s));

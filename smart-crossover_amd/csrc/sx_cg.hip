@@ -662,7 +662,7 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
     if (rc == SX_OK) rc = sx_rowblock_get(ctx, A_loc, &h->rb);
     const size_t off_ppq = 256, off_prr = off_ppq + sizeof(double) * CG_GRID, off_vec = off_prr + sizeof(double) * CG_GRID;
     const size_t bytes = off_vec + sizeof(double) * (4 * static_cast<size_t>(m) + 2 * static_cast<size_t>(n > 0 ? n : 1)) + 256;
-    if (rc == SX_OK && hipMalloc(reinterpret_cast<void **>(&h->block), bytes) != hipSuccess) {
+    if (rc == SX_OK && sx_dmalloc(reinterpret_cast<void **>(&h->block), bytes) != hipSuccess) {
         sx_set_error("hipMalloc of %zu bytes failed for the sharded projector", bytes);
         rc = SX_ERR_NOMEM;
     }
@@ -674,7 +674,7 @@ SX_API int sx_cg_shard_open(sx_ctx *ctx, const sx_matrix *A_loc, const double *x
         sx_cg_shard *h;
         ~Guard() {
             if (h) {
-                (void)hipFree(h->block);
+                (void)sx_dfree(h->block);
                 delete h;
             }
         }
@@ -812,7 +812,7 @@ SX_API int sx_cg_shard_close(sx_cg_shard *h) {
     if (!h) return SX_OK;
     sx_device_guard guard(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    if (h->block) (void)hipFree(h->block);
+    if (h->block) (void)sx_dfree(h->block);
     delete h;
     return SX_OK;
 }

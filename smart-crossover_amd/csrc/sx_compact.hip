@@ -250,7 +250,7 @@ template <class T>
 int dev_alloc_padded(sx_ctx *ctx, int64_t count, T **out) {
     *out = nullptr;
     T *d = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(T) * static_cast<size_t>(count + SX_PAD)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d), sizeof(T) * static_cast<size_t>(count + SX_PAD)));
     *out = d;
     SX_HIP(hipMemsetAsync(d + count, 0, sizeof(T) * SX_PAD, ctx->stream));
     return SX_OK;
@@ -260,12 +260,12 @@ struct scratch {
     std::vector<void *> p;
     ~scratch() {
         for (void *q : p)
-            if (q) (void)hipFree(q);
+            if (q) (void)sx_dfree(q);
     }
     template <class T>
     int get(size_t count, T **out) {
         void *d = nullptr;
-        SX_HIP(hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+        SX_HIP(sx_dmalloc(&d, sizeof(T) * (count ? count : 1)));
         p.push_back(d);
         *out = static_cast<T *>(d);
         return SX_OK;

@@ -852,12 +852,12 @@ __global__ void k_tb_eta_t_fin(int G, double *__restrict__ v, const double *__re
 struct DevBufs {
     std::vector<void *> p;
     ~DevBufs() {
-        for (void *q : p) (void)hipFree(q);
+        for (void *q : p) (void)sx_dfree(q);
     }
     template <class T>
     int get(size_t count, T **out) {
         void *d = nullptr;
-        if (hipMalloc(&d, sizeof(T) * (count ? count : 1)) != hipSuccess) {
+        if (sx_dmalloc(&d, sizeof(T) * (count ? count : 1)) != hipSuccess) {
             sx_set_error("hipMalloc of %zu bytes failed in the sparse crossover", sizeof(T) * count);
             return SX_ERR_NOMEM;
         }
@@ -938,7 +938,7 @@ struct TbSlots {
     ~TbSlots() {
         for (void *q : {(void *)(T_own ? T : nullptr), (void *)xJ, (void *)lJ, (void *)uJ, (void *)cJ, (void *)dJ, (void *)d1, (void *)rowbuf, (void *)vbuf, (void *)ebG,
                         (void *)ebS, (void *)varJ, (void *)statJ, (void *)s0, (void *)sbase, (void *)elist})
-            (void)hipFree(q);
+            (void)sx_dfree(q);
     }
     void swap_with(TbSlots &o) {
         std::swap(mp, o.mp); std::swap(cap, o.cap); std::swap(T_own, o.T_own); std::swap(T, o.T); std::swap(xJ, o.xJ); std::swap(lJ, o.lJ); std::swap(uJ, o.uJ);
@@ -960,7 +960,7 @@ struct TbSlots {
             nw.T_own = nw.T == nullptr;
         }
 #define TB_GET(field, count)                                                                                                       \
-    if (hipMalloc(reinterpret_cast<void **>(&nw.field), sizeof(*nw.field) * (count)) != hipSuccess) {                               \
+    if (sx_dmalloc(reinterpret_cast<void **>(&nw.field), sizeof(*nw.field) * (count)) != hipSuccess) {                               \
         sx_set_error("hipMalloc of %zu bytes failed in the sparse crossover (tableau of %lld columns over %lld positions)",        \
                      sizeof(*nw.field) * (count), (long long)newcap, (long long)mp_);                                              \
         return SX_ERR_NOMEM;                                                                                                       \

@@ -88,10 +88,10 @@ bool sx_ctx_take_block(sx_ctx *ctx, size_t bytes, void **base, size_t *got) {
 void sx_ctx_give_block(sx_ctx *ctx, void *base, size_t bytes) {
     if (!base) return;
     if (ctx->blk && ctx->blk_bytes >= bytes) {
-        (void)hipFree(base);
+        (void)sx_dfree(base);
         return;
     }
-    if (ctx->blk) (void)hipFree(ctx->blk);
+    if (ctx->blk) (void)sx_dfree(ctx->blk);
     ctx->blk = base;
     ctx->blk_bytes = bytes;
 }
@@ -102,7 +102,7 @@ SX_API int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes) {
     SX_ENTER(ctx);
     if (bytes == 0) {
         blk_join(ctx);
-        if (ctx->blk) (void)hipFree(ctx->blk);
+        if (ctx->blk) (void)sx_dfree(ctx->blk);
         ctx->blk = nullptr;
         ctx->blk_bytes = 0;
         return SX_OK;
@@ -113,7 +113,7 @@ SX_API int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes) {
     size_t free_b = 0, total_b = 0;
     SX_HIP(hipMemGetInfo(&free_b, &total_b));
     if (ctx->blk) { // (replaced by the larger one: its memory counts as free)
-        (void)hipFree(ctx->blk);
+        (void)sx_dfree(ctx->blk);
         free_b += ctx->blk_bytes;
         ctx->blk = nullptr;
         ctx->blk_bytes = 0;
@@ -123,7 +123,7 @@ SX_API int sx_ctx_prefetch_block(sx_ctx *ctx, size_t bytes) {
     const int device = ctx->device;
     ctx->blk_thread = new (std::nothrow) std::thread([ctx, device, bytes]() {
         void *p = nullptr;
-        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+        if (hipSetDevice(device) != hipSuccess || sx_dmalloc(&p, bytes) != hipSuccess) {
             p = nullptr;
             (void)hipGetLastError();
         }
@@ -138,14 +138,14 @@ SX_API int sx_ctx_destroy(sx_ctx *ctx) {
     sx_device_guard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     blk_join(ctx);
-    if (ctx->blk) (void)hipFree(ctx->blk);
-    if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->ws2) (void)hipFree(ctx->ws2);
-    if (ctx->ws3) (void)hipFree(ctx->ws3);
-    if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
-    if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
-    if (ctx->nd_order) (void)hipFree(ctx->nd_order);
-    if (ctx->nd_y) (void)hipFree(ctx->nd_y);
+    if (ctx->blk) (void)sx_dfree(ctx->blk);
+    if (ctx->ws) (void)sx_dfree(ctx->ws);
+    if (ctx->ws2) (void)sx_dfree(ctx->ws2);
+    if (ctx->ws3) (void)sx_dfree(ctx->ws3);
+    if (ctx->spare_binv) (void)sx_dfree(ctx->spare_binv);
+    if (ctx->nd_tree) (void)sx_dfree(ctx->nd_tree);
+    if (ctx->nd_order) (void)sx_dfree(ctx->nd_order);
+    if (ctx->nd_y) (void)sx_dfree(ctx->nd_y);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->t_made)
         for (int i = 0; i < 8; ++i) {
@@ -249,12 +249,12 @@ static int reserve_block(sx_ctx *ctx, void **block, size_t *have, size_t bytes) 
     if (bytes <= *have) return SX_OK;
     // the old block may still be in use by enqueued kernels
     SX_HIP(hipStreamSynchronize(ctx->stream));
-    if (*block) SX_HIP(hipFree(*block));
+    if (*block) SX_HIP(sx_dfree(*block));
     *block = nullptr;
     *have = 0;
     size_t want = std::max(bytes, static_cast<size_t>(1) << 20);
     want = (want + 255) & ~static_cast<size_t>(255);
-    SX_HIP(hipMalloc(block, want));
+    SX_HIP(sx_dmalloc(block, want));
     *have = want;
     return SX_OK;
 }
@@ -271,7 +271,7 @@ SX_API int sx_malloc(sx_ctx *ctx, size_t bytes, void **dev_out) {
     SX_REQUIRE(dev_out != nullptr, "dev_out is NULL");
     *dev_out = nullptr;
     if (bytes == 0) bytes = 8;
-    SX_HIP(hipMalloc(dev_out, bytes));
+    SX_HIP(sx_dmalloc(dev_out, bytes));
     return SX_OK;
 }
 
@@ -279,7 +279,7 @@ SX_API int sx_free(sx_ctx *ctx, void *dev) {
     SX_ENTER(ctx);
     if (!dev) return SX_OK;
     SX_HIP(hipStreamSynchronize(ctx->stream));
-    SX_HIP(hipFree(dev));
+    SX_HIP(sx_dfree(dev));
     return SX_OK;
 }
 
@@ -397,7 +397,7 @@ static int upload_padded(sx_ctx *ctx, const T *host, int64_t count, T **dev_out)
     *dev_out = nullptr;
     size_t bytes = static_cast<size_t>(count + SX_PAD) * sizeof(T);
     T *d = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&d), bytes));
     *dev_out = d;
     SX_HIP(hipMemsetAsync(d + count, 0, SX_PAD * sizeof(T), ctx->stream));
     if (count)
@@ -564,7 +564,7 @@ SX_API int sx_matrix_destroy(sx_matrix *A) {
     void *ptrs[9] = {A->csr_ptr, A->csr_idx,   A->csr_val,   A->csc_ptr,   A->csc_idx,
                      A->csc_val, A->csr_tiles, A->csc_tiles, A->csc_win_lo};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)sx_dfree(p);
     sx_rowblock_free(A->rb);
     sx_slabs_free(A->slabs[0]);
     sx_slabs_free(A->slabs[1]);

@@ -353,15 +353,15 @@ SX_API int sx_denselu_create_dev(sx_ctx *ctx, int64_t n, sx_denselu **out) {
         sx_denselu *h;
         ~Guard() {
             if (h) {
-                (void)hipFree(h->a);
-                (void)hipFree(h->ipiv);
+                (void)sx_dfree(h->a);
+                (void)sx_dfree(h->ipiv);
                 delete h;
             }
         }
     } guard{h};
     const size_t bytes = sizeof(double) * static_cast<size_t>(h->ld) * static_cast<size_t>(n);
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->a), bytes));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * 3 * static_cast<size_t>(n)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->a), bytes));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->ipiv), sizeof(int32_t) * 3 * static_cast<size_t>(n)));
     h->rep = h->ipiv + n;
     h->perm = h->rep + n;
     SX_HIP(hipMemsetAsync(h->a, 0, bytes, ctx->stream));
@@ -393,9 +393,9 @@ SX_API int sx_denselu_destroy(sx_denselu *h) {
     if (!h) return SX_OK;
     sx_device_guard guard(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    (void)hipFree(h->a);
-    (void)hipFree(h->ipiv);
-    (void)hipFree(h->tmp);
+    (void)sx_dfree(h->a);
+    (void)sx_dfree(h->ipiv);
+    (void)sx_dfree(h->tmp);
     delete h;
     return SX_OK;
 }
@@ -464,10 +464,10 @@ SX_API int sx_denselu_solve_dev(sx_denselu *h, int trans, int64_t nrhs, double *
     const size_t need = static_cast<size_t>(n) * static_cast<size_t>(nrhs);
     if (need > h->tmp_cap) {
         SX_HIP(hipStreamSynchronize(s));
-        (void)hipFree(h->tmp);
+        (void)sx_dfree(h->tmp);
         h->tmp = nullptr;
         h->tmp_cap = 0;
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&h->tmp), sizeof(double) * need));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&h->tmp), sizeof(double) * need));
         h->tmp_cap = need;
     }
     const unsigned pg = static_cast<unsigned>(std::min<int64_t>((static_cast<int64_t>(need) + 255) / 256, 1 << 16));

@@ -117,6 +117,16 @@ struct sx_ctx {
                                // than the 1e7 gathered lines they replace; profiles/r03/experiments/k2_long_row_staging.md): off
 };
 
+// Device memory of the library (sx_pool.hip): hipMalloc / hipFree with freed blocks kept for the next request of their size
+// class.  sx_dfree synchronises the device as hipFree does; nullptr is fine.
+hipError_t sx_pool_malloc(void **p, size_t bytes);
+hipError_t sx_pool_free(void *p);
+template <class T>
+inline hipError_t sx_dmalloc(T **p, size_t bytes) {
+    return sx_pool_malloc(reinterpret_cast<void **>(p), bytes);
+}
+inline hipError_t sx_dfree(void *p) { return sx_pool_free(p); }
+
 int sx_reserve(sx_ctx *ctx, size_t bytes);  // ensure ctx->ws holds >= bytes
 // the context's big block (sx_ctx.hip): take hands it to the caller when it holds >= bytes (waits for a pending
 // allocation; false: none of that size), give hands one back (the larger of the two is kept)
@@ -134,7 +144,7 @@ struct sx_arena {
     std::vector<void *> extra;
     explicit sx_arena(sx_ctx *c) : ctx(c) {}
     ~sx_arena() {
-        for (void *q : extra) (void)hipFree(q);
+        for (void *q : extra) (void)sx_dfree(q);
     }
     template <class T>
     int get(size_t count, T **out) {
@@ -145,7 +155,7 @@ struct sx_arena {
             return SX_OK;
         }
         void *d = nullptr;
-        SX_HIP(hipMalloc(&d, need));
+        SX_HIP(sx_dmalloc(&d, need));
         extra.push_back(d);
         *out = static_cast<T *>(d);
         return SX_OK;
@@ -241,14 +251,14 @@ struct sx_stage {
     std::vector<void *> bufs;
     explicit sx_stage(sx_ctx *c) : ctx(c) {}
     ~sx_stage() {
-        for (void *p : bufs) (void)hipFree(p);
+        for (void *p : bufs) (void)sx_dfree(p);
     }
     // allocate `bytes` on the device; copy from src when src != nullptr
     int in(const void *src, size_t bytes, void **out) {
         *out = nullptr;
         if (bytes == 0) bytes = 8;
         void *p = nullptr;
-        SX_HIP(hipMalloc(&p, bytes));
+        SX_HIP(sx_dmalloc(&p, bytes));
         bufs.push_back(p);
         if (src) SX_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         *out = p;

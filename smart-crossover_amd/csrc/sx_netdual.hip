@@ -1346,15 +1346,15 @@ SX_API int sx_netdual_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, cons
     // tree this one ends with)
     bool kept = ctx->nd_tree && ctx->nd_tree_V == V && ctx->nd_tree_root == sh.root;
     if (!kept) {
-        if (ctx->nd_tree) (void)hipFree(ctx->nd_tree);
-        if (ctx->nd_order) (void)hipFree(ctx->nd_order);
-        if (ctx->nd_y) (void)hipFree(ctx->nd_y);
+        if (ctx->nd_tree) (void)sx_dfree(ctx->nd_tree);
+        if (ctx->nd_order) (void)sx_dfree(ctx->nd_order);
+        if (ctx->nd_y) (void)sx_dfree(ctx->nd_y);
         ctx->nd_tree = ctx->nd_order = nullptr;
         ctx->nd_y = nullptr;
         ctx->nd_tree_V = 0;
-        SX_HIP(hipMalloc(&ctx->nd_tree, sizeof(int4) * static_cast<size_t>(V)));
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->nd_order), sizeof(int32_t) * static_cast<size_t>(V)));
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->nd_y), sizeof(double) * static_cast<size_t>(V)));
+        SX_HIP(sx_dmalloc(&ctx->nd_tree, sizeof(int4) * static_cast<size_t>(V)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&ctx->nd_order), sizeof(int32_t) * static_cast<size_t>(V)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&ctx->nd_y), sizeof(double) * static_cast<size_t>(V)));
     }
     P.nd = static_cast<int4 *>(ctx->nd_tree);
     P.order = ctx->nd_order;

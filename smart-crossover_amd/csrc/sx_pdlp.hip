@@ -441,10 +441,10 @@ SX_API int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const d
     const size_t doubles = 5 * nn + 5 * mm /* xbar xsum xr dc dc2 | ysum yr dr dr2 w */ + nn /* tmp n */ + mm /* tmp m */ +
                            static_cast<size_t>(gr + gc) * PD_NPART + 64;
     char *block = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&block), doubles * sizeof(double) + 1024));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&block), doubles * sizeof(double) + 1024));
     struct Free {
         void *p;
-        ~Free() { (void)hipFree(p); }
+        ~Free() { (void)sx_dfree(p); }
     } guard{block};
     SX_HIP(hipMemsetAsync(block, 0, doubles * sizeof(double) + 1024, s));
     PdState *st = reinterpret_cast<PdState *>(block);

@@ -412,7 +412,7 @@ namespace {
 constexpr double RB_LONG_COST = 3.0;
 int rb_build_order(sx_ctx *ctx, const sx_rowblock *rb, int mode) {
     rb->order_tried = mode ? mode : 1000;
-    (void)hipFree(rb->order);
+    (void)sx_dfree(rb->order);
     rb->order = nullptr;
     rb->order_n = 0;
     const int64_t nst = rb->nst;
@@ -462,7 +462,7 @@ int rb_build_order(sx_ctx *ctx, const sx_rowblock *rb, int mode) {
     std::vector<int32_t> order(most * 8, -1);
     for (int x = 0; x < 8; ++x)
         for (size_t k = 0; k < per[x].size(); ++k) order[k * 8 + static_cast<size_t>(x)] = per[x][k];
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->order), sizeof(int32_t) * order.size()));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->order), sizeof(int32_t) * order.size()));
     SX_HIP(hipMemcpyAsync(rb->order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, ctx->stream));
     SX_HIP(hipStreamSynchronize(ctx->stream));
     rb->order_n = static_cast<int64_t>(order.size());

@@ -268,13 +268,13 @@ struct Temps {
     std::vector<void *> p;
     ~Temps() {
         for (void *q : p)
-            if (q) (void)hipFree(q);
+            if (q) (void)sx_dfree(q);
     }
     template <class T>
     int get(size_t count, T **out, bool zero, hipStream_t s) {
         void *d = nullptr;
         const size_t bytes = sizeof(T) * (count ? count : 1);
-        SX_HIP(hipMalloc(&d, bytes));
+        SX_HIP(sx_dmalloc(&d, bytes));
         p.push_back(d);
         if (zero) SX_HIP(hipMemsetAsync(d, 0, bytes, s));
         *out = static_cast<T *>(d);
@@ -423,11 +423,11 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
     rb->nent = nent;
     rb->nnz = nnz;
     rb->windowed = static_cast<int64_t>(totals[0]);
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->idx), sizeof(int32_t) * static_cast<size_t>(nent + 8)));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->val), sizeof(double) * static_cast<size_t>(nent + 8)));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->rowstart), sizeof(uint16_t) * static_cast<size_t>(ncells) * RB_RS_STRIDE));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->chunks), sizeof(sx_rb_chunk) * static_cast<size_t>(nchunks)));
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->st), sizeof(sx_rb_supertile) * static_cast<size_t>(nst)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->idx), sizeof(int32_t) * static_cast<size_t>(nent + 8)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->val), sizeof(double) * static_cast<size_t>(nent + 8)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->rowstart), sizeof(uint16_t) * static_cast<size_t>(ncells) * RB_RS_STRIDE));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->chunks), sizeof(sx_rb_chunk) * static_cast<size_t>(nchunks)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->st), sizeof(sx_rb_supertile) * static_cast<size_t>(nst)));
     SX_HIP(hipMemsetAsync(rb->idx, 0, sizeof(int32_t) * static_cast<size_t>(nent + 8), s));
     SX_HIP(hipMemsetAsync(rb->val, 0, sizeof(double) * static_cast<size_t>(nent + 8), s));
     uint32_t *rowhist;
@@ -466,10 +466,10 @@ int build(sx_ctx *ctx, const sx_matrix *A, bool force, sx_rowblock **out) {
             int lcur = 0;
             SX_TRY(sx_sort_pairs(ctx, static_cast<int64_t>(nl), lkey, lpay, lhist, loffs, (cbits + 7) / 8, &lcur));
             rb->nl = static_cast<int64_t>(nl);
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lcol), sizeof(int32_t) * static_cast<size_t>(nl)));
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->le), sizeof(int32_t) * static_cast<size_t>(nl)));
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lval), sizeof(double) * static_cast<size_t>(nl)));
-            SX_HIP(hipMalloc(reinterpret_cast<void **>(&rb->lprod), sizeof(double) * static_cast<size_t>(nent + 8)));
+            SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->lcol), sizeof(int32_t) * static_cast<size_t>(nl)));
+            SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->le), sizeof(int32_t) * static_cast<size_t>(nl)));
+            SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->lval), sizeof(double) * static_cast<size_t>(nl)));
+            SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&rb->lprod), sizeof(double) * static_cast<size_t>(nent + 8)));
             SX_HIP(hipMemsetAsync(rb->lprod, 0, sizeof(double) * static_cast<size_t>(nent + 8), s));
             hipLaunchKernelGGL(k_rb_long_lists, dim3(grid1d(static_cast<int64_t>(nl))), dim3(SX_WG), 0, s, static_cast<int64_t>(nl),
                                lkey[lcur], lpay[lcur], rb->val, rb->lcol, rb->le, rb->lval);
@@ -491,7 +491,7 @@ void sx_rowblock_free(sx_rowblock *rb) {
     if (!rb) return;
     void *ptrs[10] = {rb->st, rb->chunks, rb->rowstart, rb->idx, rb->val, rb->lcol, rb->le, rb->lval, rb->lprod, rb->order};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)sx_dfree(p);
     delete rb;
 }
 

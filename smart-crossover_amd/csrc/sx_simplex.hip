@@ -1225,11 +1225,11 @@ struct DevBufs {
     size_t arena_bytes = 0, used = 0;
     ~DevBufs() {
         for (void *q : p)
-            if (q) (void)hipFree(q);
+            if (q) (void)sx_dfree(q);
     }
     int reserve(size_t bytes) {
         void *d = nullptr;
-        SX_HIP(hipMalloc(&d, bytes));
+        SX_HIP(sx_dmalloc(&d, bytes));
         p.push_back(d);
         arena = static_cast<char *>(d);
         arena_bytes = bytes;
@@ -1245,7 +1245,7 @@ struct DevBufs {
             return SX_OK;
         }
         void *d = nullptr;
-        SX_HIP(hipMalloc(&d, want));
+        SX_HIP(sx_dmalloc(&d, want));
         p.push_back(d);
         *out = static_cast<T *>(d);
         return SX_OK;
@@ -1299,7 +1299,7 @@ SX_API int sx_simplex_session_destroy(sx_simplex_session *session) {
     if (session->Binv) { // parked in the context for the next session of the same size (one spare at most)
         sx_ctx *ctx = session->ctx;
         (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->spare_binv) (void)hipFree(ctx->spare_binv);
+        if (ctx->spare_binv) (void)sx_dfree(ctx->spare_binv);
         ctx->spare_binv = session->Binv;
         ctx->spare_binv_m = session->m;
     }
@@ -1411,7 +1411,7 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
     P.s_keep = nullptr;
     if (session) { // the inverse outlives the call
         if (session->m != m || session->Binv == nullptr) {
-            if (session->Binv) SX_HIP(hipFree(session->Binv));
+            if (session->Binv) SX_HIP(sx_dfree(session->Binv));
             session->Binv = nullptr;
             session->valid = false;
             session->m = m;
@@ -1420,7 +1420,7 @@ static int spx_solve(sx_ctx *ctx, sx_simplex_session *session, const sx_matrix *
                 ctx->spare_binv = nullptr;
                 ctx->spare_binv_m = 0;
             } else {
-                SX_HIP(hipMalloc(reinterpret_cast<void **>(&session->Binv),
+                SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&session->Binv),
                                  sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(m) + 1)));
             }
         }

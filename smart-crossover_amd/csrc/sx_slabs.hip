@@ -89,7 +89,7 @@ int build(sx_ctx *ctx, const int64_t *ptr, const int32_t *idx, const double *val
         void *tmp[3] = {nullptr, nullptr, nullptr};
         ~Guard() {
             for (void *p : tmp)
-                if (p) (void)hipFree(p);
+                if (p) (void)sx_dfree(p);
             if (S) sx_slabs_free(S);
         }
     } guard{S};
@@ -104,9 +104,9 @@ int build(sx_ctx *ctx, const int64_t *ptr, const int32_t *idx, const double *val
     int64_t *cnt = nullptr;
     int *desc = nullptr;
     SlabDev *dev = nullptr;
-    SX_HIP(hipMalloc(&guard.tmp[0], sizeof(int64_t) * static_cast<size_t>(R) * static_cast<size_t>(nseg)));
-    SX_HIP(hipMalloc(&guard.tmp[1], sizeof(int)));
-    SX_HIP(hipMalloc(&guard.tmp[2], sizeof(SlabDev) * static_cast<size_t>(R)));
+    SX_HIP(sx_dmalloc(&guard.tmp[0], sizeof(int64_t) * static_cast<size_t>(R) * static_cast<size_t>(nseg)));
+    SX_HIP(sx_dmalloc(&guard.tmp[1], sizeof(int)));
+    SX_HIP(sx_dmalloc(&guard.tmp[2], sizeof(SlabDev) * static_cast<size_t>(R)));
     cnt = static_cast<int64_t *>(guard.tmp[0]);
     desc = static_cast<int *>(guard.tmp[1]);
     dev = static_cast<SlabDev *>(guard.tmp[2]);
@@ -121,13 +121,13 @@ int build(sx_ctx *ctx, const int64_t *ptr, const int32_t *idx, const double *val
     for (int s = 0; s < R; ++s) {
         sx_slab &L = S->slab[s];
         L.off = static_cast<int64_t>(s) * width;
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&L.ptr), sizeof(int64_t) * static_cast<size_t>(nseg + 9)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&L.ptr), sizeof(int64_t) * static_cast<size_t>(nseg + 9)));
         SX_HIP(hipMemsetAsync(L.ptr, 0, sizeof(int64_t) * static_cast<size_t>(nseg + 9), st));
         SX_TRY(sx_scan_exclusive(ctx, cnt + static_cast<int64_t>(s) * nseg, nseg, L.ptr));
         SX_HIP(hipMemcpyAsync(&L.nnz, L.ptr + nseg, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         SX_HIP(hipStreamSynchronize(st));
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&L.idx), sizeof(int32_t) * static_cast<size_t>(L.nnz + 8)));
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&L.val), sizeof(double) * static_cast<size_t>(L.nnz + 8)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&L.idx), sizeof(int32_t) * static_cast<size_t>(L.nnz + 8)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&L.val), sizeof(double) * static_cast<size_t>(L.nnz + 8)));
         SX_HIP(hipMemsetAsync(L.idx, 0, sizeof(int32_t) * static_cast<size_t>(L.nnz + 8), st));
         SX_HIP(hipMemsetAsync(L.val, 0, sizeof(double) * static_cast<size_t>(L.nnz + 8), st));
         host[static_cast<size_t>(s)] = SlabDev{L.ptr, L.idx, L.val};
@@ -145,7 +145,7 @@ int build(sx_ctx *ctx, const int64_t *ptr, const int32_t *idx, const double *val
         sx_set_error("operand slabs hold %lld of %lld entries", (long long)total, (long long)nnz);
         return SX_ERR_HIP;
     }
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&S->carry), sizeof(double) * static_cast<size_t>(nseg + 8)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&S->carry), sizeof(double) * static_cast<size_t>(nseg + 8)));
     SX_HIP(hipStreamSynchronize(st));
     guard.S = nullptr;
     *out = S;
@@ -160,11 +160,11 @@ void sx_slabs_free(sx_slabs *S) {
         for (int s = 0; s < S->R; ++s) {
             void *p[4] = {S->slab[s].ptr, S->slab[s].idx, S->slab[s].val, S->slab[s].tiles};
             for (void *q : p)
-                if (q) (void)hipFree(q);
+                if (q) (void)sx_dfree(q);
         }
         delete[] S->slab;
     }
-    if (S->carry) (void)hipFree(S->carry);
+    if (S->carry) (void)sx_dfree(S->carry);
     delete S;
 }
 

@@ -49,18 +49,18 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
     if (imbalance_out) *imbalance_out = 1.0;
     int64_t *tiles = nullptr;
     if (nseg == 0) {
-        SX_HIP(hipMalloc(reinterpret_cast<void **>(&tiles), sizeof(int64_t)));
+        SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&tiles), sizeof(int64_t)));
         SX_HIP(hipMemsetAsync(tiles, 0, sizeof(int64_t), ctx->stream));
         *tiles_out = tiles;
         return SX_OK;
     }
     uint8_t *flag = nullptr;
     int64_t *idx = nullptr, *count = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&flag), static_cast<size_t>(nseg)));
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&flag), static_cast<size_t>(nseg)));
     int rc = SX_OK;
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void **>(&idx), sizeof(int64_t) * nseg)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void **>(&count), sizeof(int64_t))) != hipSuccess) {
+    if ((e = sx_dmalloc(reinterpret_cast<void **>(&idx), sizeof(int64_t) * nseg)) != hipSuccess ||
+        (e = sx_dmalloc(reinterpret_cast<void **>(&count), sizeof(int64_t))) != hipSuccess) {
         sx_set_error("hipMalloc failed while building tiles: %s", hipGetErrorString(e));
         rc = SX_ERR_NOMEM;
     }
@@ -84,7 +84,7 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
         }
     }
     if (rc == SX_OK) {
-        if (hipMalloc(reinterpret_cast<void **>(&tiles), sizeof(int64_t) * (nt + 1)) != hipSuccess) {
+        if (sx_dmalloc(reinterpret_cast<void **>(&tiles), sizeof(int64_t) * (nt + 1)) != hipSuccess) {
             sx_set_error("hipMalloc failed for %lld tiles", (long long)nt);
             rc = SX_ERR_NOMEM;
         } else if (hipMemcpyAsync(tiles, idx, sizeof(int64_t) * nt, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
@@ -111,11 +111,11 @@ int sx_build_tiles(sx_ctx *ctx, const int64_t *ptr_dev, int64_t nseg, int64_t **
             }
         }
     }
-    if (flag) (void)hipFree(flag);
-    if (idx) (void)hipFree(idx);
-    if (count) (void)hipFree(count);
+    if (flag) (void)sx_dfree(flag);
+    if (idx) (void)sx_dfree(idx);
+    if (count) (void)sx_dfree(count);
     if (rc != SX_OK) {
-        if (tiles) (void)hipFree(tiles);
+        if (tiles) (void)sx_dfree(tiles);
         return rc;
     }
     *tiles_out = tiles;

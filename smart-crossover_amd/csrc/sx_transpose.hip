@@ -67,10 +67,10 @@ template <class T>
 int alloc_padded(int64_t count, T **out, hipStream_t s) {
     void *p = nullptr;
     const size_t bytes = sizeof(T) * static_cast<size_t>(count + SX_PAD);
-    SX_HIP(hipMalloc(&p, bytes));
+    SX_HIP(sx_dmalloc(&p, bytes));
     if (hipMemsetAsync(static_cast<char *>(p) + sizeof(T) * static_cast<size_t>(count), 0, sizeof(T) * SX_PAD, s) !=
         hipSuccess) {
-        (void)hipFree(p);
+        (void)sx_dfree(p);
         sx_set_error("hipMemsetAsync failed");
         return SX_ERR_HIP;
     }
@@ -99,10 +99,10 @@ int sx_transpose_dev(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int64
         if ((rc = alloc_padded(n + 1, &colptr, s)) != SX_OK) break;
         if ((rc = alloc_padded(nnz, &rows, s)) != SX_OK) break;
         if ((rc = alloc_padded(nnz, &vals, s)) != SX_OK) break;
-        if (hipMalloc(reinterpret_cast<void **>(&cnt), sizeof(unsigned long long) * static_cast<size_t>(n + 1)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&key), sizeof(double) * static_cast<size_t>(nnz + 1)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&ranked), sizeof(int64_t) * static_cast<size_t>(nnz + 1)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&order), sizeof(int64_t) * static_cast<size_t>(nnz + 1)) != hipSuccess) {
+        if (sx_dmalloc(reinterpret_cast<void **>(&cnt), sizeof(unsigned long long) * static_cast<size_t>(n + 1)) != hipSuccess ||
+            sx_dmalloc(reinterpret_cast<void **>(&key), sizeof(double) * static_cast<size_t>(nnz + 1)) != hipSuccess ||
+            sx_dmalloc(reinterpret_cast<void **>(&ranked), sizeof(int64_t) * static_cast<size_t>(nnz + 1)) != hipSuccess ||
+            sx_dmalloc(reinterpret_cast<void **>(&order), sizeof(int64_t) * static_cast<size_t>(nnz + 1)) != hipSuccess) {
             sx_set_error("out of device memory while transposing (%lld entries)", (long long)nnz);
             rc = SX_ERR_NOMEM;
             break;
@@ -123,14 +123,14 @@ int sx_transpose_dev(sx_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int64
             rc = SX_ERR_HIP;
         }
     } while (0);
-    if (cnt) (void)hipFree(cnt);
-    if (key) (void)hipFree(key);
-    if (ranked) (void)hipFree(ranked);
-    if (order) (void)hipFree(order);
+    if (cnt) (void)sx_dfree(cnt);
+    if (key) (void)sx_dfree(key);
+    if (ranked) (void)sx_dfree(ranked);
+    if (order) (void)sx_dfree(order);
     if (rc != SX_OK) {
-        if (colptr) (void)hipFree(colptr);
-        if (rows) (void)hipFree(rows);
-        if (vals) (void)hipFree(vals);
+        if (colptr) (void)sx_dfree(colptr);
+        if (rows) (void)sx_dfree(rows);
+        if (vals) (void)sx_dfree(vals);
         return rc;
     }
     *colptr_out = colptr;

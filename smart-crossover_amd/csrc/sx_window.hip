@@ -102,9 +102,9 @@ int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int
     *useful_out = 0;
     if (ntiles == 0 || bound < SXL_CAP) return SX_OK;
     int32_t *wl = nullptr, *stat = nullptr;
-    SX_HIP(hipMalloc(reinterpret_cast<void **>(&wl), sizeof(int32_t) * ntiles));
-    if (hipMalloc(reinterpret_cast<void **>(&stat), sizeof(int32_t) * 3 * ntiles) != hipSuccess) {
-        (void)hipFree(wl);
+    SX_HIP(sx_dmalloc(reinterpret_cast<void **>(&wl), sizeof(int32_t) * ntiles));
+    if (sx_dmalloc(reinterpret_cast<void **>(&stat), sizeof(int32_t) * 3 * ntiles) != hipSuccess) {
+        (void)sx_dfree(wl);
         sx_set_error("out of device memory for the window statistics");
         return SX_ERR_NOMEM;
     }
@@ -115,9 +115,9 @@ int sx_window_setup(sx_ctx *ctx, const int64_t *tiles, int64_t ntiles, const int
                     hipMemcpyAsync(h.data(), stat, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream) ==
                         hipSuccess &&
                     hipStreamSynchronize(ctx->stream) == hipSuccess;
-    (void)hipFree(stat);
+    (void)sx_dfree(stat);
     if (!ok) {
-        (void)hipFree(wl);
+        (void)sx_dfree(wl);
         sx_set_error("window table kernel failed");
         return SX_ERR_HIP;
     }

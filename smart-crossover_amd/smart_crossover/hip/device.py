@@ -33,6 +33,8 @@ class Context:
     """One HIP device + stream + scratch space (``sx_ctx``)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
+        from . import host_threads
+        host_threads.fit_to_quota()   # (BLAS / OpenMP workers beyond the CPU quota get the launching thread throttled)
         self._lib = _l.load()
         h = C.c_void_p()
         _l.check(self._lib.sx_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
@@ -568,6 +570,19 @@ class SimplexSession:
 
 
 _default_ctx: Optional[Context] = None
+
+
+def pool_trim() -> None:
+    """Hand the device memory the library keeps for its next allocations back to the driver (``sx_pool_trim``)."""
+    _l.check(_l.load().sx_pool_trim())
+
+
+def pool_stats() -> dict:
+    """Bytes kept / in use by the library's device memory pool and requests served by it / by the driver."""
+
+    v = [C.c_uint64(0) for _ in range(4)]
+    _l.check(_l.load().sx_pool_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("cached_bytes", "live_bytes", "hits", "misses"), (int(x.value) for x in v)))
 
 
 def default_context() -> Context:

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "sx_marker_elapsed": (_int, [_vp, _int, _int, C.POINTER(C.c_float)]),
     "sx_ctx_sync_device": (_int, [_vp]),
     "sx_ctx_prefetch_block": (_int, [_vp, _sz]),
+    "sx_pool_trim": (_int, []),
+    "sx_pool_stats": (_int, [C.POINTER(C.c_uint64)] * 4),
     "sx_matrix_create_single": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, C.POINTER(_vp)]),
     "sx_matrix_create": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "sx_matrix_destroy": (_int, [_vp]),

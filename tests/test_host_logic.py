@@ -400,3 +400,33 @@ def test_barrier_without_crossover_returns_a_consistent_interior_point():
     assert np.all(lp.A @ out.x <= lp.b + 1e-5) and np.all(out.x >= lp.l - 1e-7) and np.all(out.x <= lp.u + 1e-7)
     # an interior point: the variables that vanish at the vertex are tiny but strictly inside their bounds
     assert np.count_nonzero((out.x > lp.l) & (out.x < lp.l + 1e-6)) > 100
+
+
+def test_host_thread_pools_are_only_ever_cut(monkeypatch):
+    """smart_crossover/hip/host_threads.py: the CPU quota is read from the cgroup / affinity mask, BLAS / OpenMP pools
+    larger than a quarter of it are cut, smaller ones stay, SX_BLAS_THREADS=0 leaves everything alone."""
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    from smart_crossover.hip import host_threads as ht
+    quota = ht.cpu_quota()
+    assert 1 <= quota <= (os.cpu_count() or 1)
+    before = {p["filepath"]: p["num_threads"] for p in threadpoolctl.threadpool_info()}
+    try:
+        monkeypatch.setenv("SX_BLAS_THREADS", "0")
+        rec = ht.fit_to_quota(force=True)
+        assert rec["limit"] is None and rec["pools"] == []
+        assert {p["filepath"]: p["num_threads"] for p in threadpoolctl.threadpool_info()} == before
+        monkeypatch.setenv("SX_BLAS_THREADS", "auto")
+        rec = ht.fit_to_quota(force=True)
+        limit = max(1, quota // 4)
+        for p in threadpoolctl.threadpool_info():
+            assert p["num_threads"] == min(before[p["filepath"]], limit)
+        monkeypatch.setenv("SX_BLAS_THREADS", "1")
+        ht.fit_to_quota(force=True)
+        assert all(p["num_threads"] == 1 for p in threadpoolctl.threadpool_info())
+        monkeypatch.setenv("SX_BLAS_THREADS", "auto")      # (never raises a pool again)
+        ht.fit_to_quota(force=True)
+        assert all(p["num_threads"] == 1 for p in threadpoolctl.threadpool_info())
+    finally:
+        for lib in threadpoolctl.ThreadpoolController().lib_controllers:
+            if lib.filepath in before:
+                lib.set_num_threads(before[lib.filepath])
