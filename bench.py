@@ -523,6 +523,9 @@ def _heartbeat():
 
 def main():
     _heartbeat()
+    if os.environ.get("SX_BENCH_DUMP_AFTER"):      # debugging aid: Python stacks of all threads to stderr after N seconds, repeated
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SX_BENCH_DUMP_AFTER"]), repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -583,6 +586,8 @@ def main():
     # rehearsal of the RCCL calls that a box with one GPU allows; launch it under torch.distributed.run as well
     use_dist = world > 1 or os.environ.get("SX_BENCH_REHEARSAL") == "rccl1"
     dev_index = 0 if rehearse else local_rank
+    if rehearse:
+        os.environ["SX_DEVICE"] = "0"       # (the solver backends' default context as well)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
@@ -890,31 +895,35 @@ def main():
     # outside it rank-local (K1 walk over the rank's block), one all-gather of the records and one of the entering
     # columns per round.  Never fatal: a failure is recorded and the line goes out without it
     sharded_resolve = None
-    if use_dist and not rehearse and args.resolve_rows > 0:
+    if use_dist and args.resolve_rows > 0:
         try:
             from smart_crossover import distributed as D
             from smart_crossover.formats import GeneralLP
             rr = args.resolve_rows
             inst2 = workloads.netlib_lp(rr, 10 * rr, seed=17)
             rng2 = np.random.default_rng(18)
-            lp2 = GeneralLP(inst2.A, inst2.b, inst2.c + 0.3 * rng2.standard_normal(10 * rr), inst2.l,
+            lp2 = GeneralLP(inst2.A, inst2.b, inst2.c + 0.02 * rng2.standard_normal(10 * rr), inst2.l,
                             np.where(np.isinf(inst2.u), 30.0, inst2.u), inst2.sense)
             sh2 = D.ShardedLP(lp2, dist, D.HipOps(ctx, torch))
             tr2 = []
             fence()
             t_rs = time.perf_counter()
             x_R, y_R, R_R, basis_R, status_R, rounds_R = sh2.restricted_resolve(np.flatnonzero(inst2.x > 1e-6), solver="HIP", x_start=inst2.x, y_start=inst2.y,
-                                                                                first_method="barrier", batch=2048, opt_tol=1e-6, trace=tr2)
+                                                                                first_method="barrier", batch=2048, opt_tol=1e-6, trace=tr2, max_seconds=45.0)
             fence()
             rs_elapsed = time.perf_counter() - t_rs
-            tt = torch.tensor([rs_elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([rs_elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            sharded_resolve = {"workload": f"netlib_lp({rr}, {10 * rr}) with another cost vector; restricted LP = the point's interior columns",
+            sharded_resolve = {"workload": f"netlib_lp({rr}, {10 * rr}) with another cost vector (c + 0.02 N(0, 1): 6 rounds, 5.7 s in one process; with 0.3 N(0, 1) "
+                                           "21 rounds of ~35,000 simplex iterations, 83 s -- tools/sharded_resolve_probe.py); restricted LP = the point's interior columns; "
+                                           "stops after 45 s (status TIME_LIMIT)",
                                "status": status_R, "rounds": int(rounds_R), "columns_added": [len(t) for t in tr2],
                                "seconds": float(tt.item()), "objective": float(lp2.c[R_R] @ x_R) if status_R == "OPTIMAL" else None,
                                "exchange": f"per round: all_gather of <= 2048 (|rc|, column) records per rank + all_gather of the entering columns, {world} ranks",
                                "note": "factorisation and tableau replicated (every rank makes the same pivots); pricing sharded"}
         except Exception as exc:
+            import traceback
+            log(f"[bench] rank {rank}: sharded_resolve failed:\n{traceback.format_exc()}")
             sharded_resolve = {"failed": f"{type(exc).__name__}: {exc}"[:300]}
 
     cpu = None

@@ -546,7 +546,8 @@ class ShardedLP:
     # ---- the re-solve over column shards: restricted LP replicated, pricing of everything else rank-local ------------
     def restricted_resolve(self, start_cols, solver: str = "HIP", x_start: Optional[np.ndarray] = None,
                            y_start: Optional[np.ndarray] = None, first_method: str = "default", batch: int = 2048,
-                           opt_tol: float = 1e-6, max_rounds: int = 200, trace: Optional[list] = None, settings=None):
+                           opt_tol: float = 1e-6, max_rounds: int = 200, trace: Optional[list] = None, settings=None,
+                           max_seconds: Optional[float] = None):
         """The LP re-solve with the COLUMNS sharded (north_star: "columns shard naturally ... all-reduce for the global pricing
         minimum"; the reference's last step, lp_methods/algorithms.py:69-74, prices all columns inside its solver).  What
         a vertex needs is m columns out of n: the restricted LP over a column set R (``start_cols`` at first: the columns
@@ -558,7 +559,10 @@ class ShardedLP:
         R grows and the restricted LP is solved again FROM THE BASIS IT HAD (``sx_crossover_band_basis_dev`` factors that
         very basis; new columns non-basic at a bound).  Ends when no column outside R prices out: the vertex is optimal
         for the whole LP.  Returns (x over R, y, R, basis over R, status, rounds); ``trace`` collects the columns each
-        round added.  Factorisation and tableau are replicated ("replicas only" for those)."""
+        round added.  Factorisation and tableau are replicated ("replicas only" for those).  ``max_seconds``:
+        stop before the next re-solve once ANY rank has spent that long (the flags travel with the record counts, so all
+        ranks leave in the same round): status "TIME_LIMIT", the last vertex returned."""
+        import time
         import scipy.sparse as sp
         import torch
         from smart_crossover.formats import GeneralLP
@@ -593,33 +597,51 @@ class ShardedLP:
         R = np.flatnonzero(in_R)
         A_R = fetch(R)
         basis, x_R, y, status, rounds = None, None, None, "UNKNOWN", 0
+        t_begin = time.perf_counter()
         for rounds in range(1, max_rounds + 1):
             lp_R = GeneralLP(sp.csr_matrix(A_R), self._b_host, c_all[R], l_all[R], u_all[R], sense)
-            if basis is None:
-                ws = (np.clip(np.asarray(x_start)[R], l_all[R], u_all[R]), y_start) if x_start is not None and y_start is not None else None
-                out = solve_lp(lp_R, solver, first_method, settings, warm_start_solution=ws)
-            else:
-                out = solve_lp(lp_R, solver, "primal_simplex", settings, warm_start_basis=basis, warm_start_solution=(x_R, y))
-            status = out.status
-            if status != "OPTIMAL":
-                break
-            x_R, y, basis = np.asarray(out.x, dtype=np.float64), np.asarray(out.y, dtype=np.float64), out.basis
-            # ---- rank-local pricing of the own columns outside R: non-basic at the lower bound (at the upper one when there
-            #      is no lower), reduced cost of the wrong sign = may enter
-            rc = np.asarray(o.host(o.dual_slack(self.A_cols, o.vec(y), self.c_loc)), dtype=np.float64)
-            at_up = ~np.isfinite(l_loc) & np.isfinite(u_loc)
-            free = ~np.isfinite(l_loc) & ~np.isfinite(u_loc)
-            wrong = np.where(free, np.abs(rc) > opt_tol, np.where(at_up, rc > opt_tol, rc < -opt_tol))
-            cand = np.flatnonzero(wrong & ~in_R[cs:ce] & (l_loc != u_loc))
-            order = np.lexsort((cand, -np.abs(rc[cand])))[:batch]            # largest violation first, ties to the smaller column
-            ids_loc, score_loc = (cand[order] + cs).astype(np.int64), np.abs(rc[cand[order]])
+            # a failure on ONE rank (device memory, a refused basis ...) must not leave the others waiting in the exchange
+            # below: it is caught, travels with the record counts, and every rank leaves in this round
+            err = None
+            try:
+                if basis is None:
+                    ws = (np.clip(np.asarray(x_start)[R], l_all[R], u_all[R]), y_start) if x_start is not None and y_start is not None else None
+                    out = solve_lp(lp_R, solver, first_method, settings, warm_start_solution=ws)
+                else:
+                    out = solve_lp(lp_R, solver, "primal_simplex", settings, warm_start_basis=basis, warm_start_solution=(x_R, y))
+                status = out.status
+            except Exception as exc:        # noqa: BLE001 -- re-raised below, after the exchange
+                err, status = exc, "FAILED"
+            ids_loc, score_loc = np.zeros(0, dtype=np.int64), np.zeros(0)
+            if status == "OPTIMAL":
+                x_R, y, basis = np.asarray(out.x, dtype=np.float64), np.asarray(out.y, dtype=np.float64), out.basis
+                # ---- rank-local pricing of the own columns outside R: non-basic at the lower bound (at the upper one when
+                #      there is no lower), reduced cost of the wrong sign = may enter
+                rc = np.asarray(o.host(o.dual_slack(self.A_cols, o.vec(y), self.c_loc)), dtype=np.float64)
+                at_up = ~np.isfinite(l_loc) & np.isfinite(u_loc)
+                free = ~np.isfinite(l_loc) & ~np.isfinite(u_loc)
+                wrong = np.where(free, np.abs(rc) > opt_tol, np.where(at_up, rc > opt_tol, rc < -opt_tol))
+                cand = np.flatnonzero(wrong & ~in_R[cs:ce] & (l_loc != u_loc))
+                order = np.lexsort((cand, -np.abs(rc[cand])))[:batch]        # largest violation first, ties to the smaller column
+                ids_loc, score_loc = (cand[order] + cs).astype(np.int64), np.abs(rc[cand[order]])
             # ---- ONE exchange of the records: every rank ends with the same global list
-            cnt = self._allgather(torch.tensor([ids_loc.size], dtype=torch.int64, device=dev), [1] * world)
-            sizes = [int(v) for v in cnt.cpu()]
+            late = int(max_seconds is not None and time.perf_counter() - t_begin > max_seconds)
+            flags = torch.tensor([ids_loc.size, late, int(status != "OPTIMAL")], dtype=torch.int64, device=dev)
+            cnt = self._allgather(flags, [3] * world).cpu().numpy().reshape(world, 3)
+            if cnt[:, 2].any():              # not optimal somewhere (the same everywhere when the replicas agree): all leave
+                if err is not None:
+                    raise err
+                if status == "OPTIMAL":
+                    raise RuntimeError(f"restricted_resolve: rank(s) {np.flatnonzero(cnt[:, 2]).tolist()} left round {rounds} without an optimal vertex")
+                break
+            sizes = [int(v) for v in cnt[:, 0]]
             ids_all = self._allgather(torch.from_numpy(ids_loc).to(dev), sizes).cpu().numpy()
             score_all = self._allgather(torch.from_numpy(np.ascontiguousarray(score_loc)).to(dev), sizes).cpu().numpy()
             if ids_all.size == 0:
                 break                                                        # optimal for the whole LP
+            if cnt[:, 1].any():
+                status = "TIME_LIMIT"
+                break
             pick = np.lexsort((ids_all, -score_all))[:batch]
             add = np.sort(ids_all[pick])
             if trace is not None:

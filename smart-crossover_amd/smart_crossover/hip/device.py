@@ -593,5 +593,6 @@ def default_context() -> Context:
         import os
         if _l.device_count() == 0:
             raise _l.SxLibraryError("no HIP device visible: the smart_crossover HIP path needs an MI355X")
-        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+        # one process per GPU: the rank's own device (SX_DEVICE overrides it: several ranks rehearsing on one GPU)
+        _default_ctx = Context(int(os.environ.get("SX_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     return _default_ctx

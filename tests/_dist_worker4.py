@@ -56,6 +56,32 @@ def main():
     kw = {}
     if solver == "HIP":      # the device's first solve starts at the point (first-order stage + sparse crossover), not at the slack basis
         kw = {"x_start": problem.point[0], "y_start": problem.point[1], "first_method": "barrier"}
+    fail_rank = os.environ.get("SX_TEST_FAIL_RANK")
+    if fail_rank is not None:    # one rank's replicated solve fails in its second round: every rank must leave, none may hang
+        from smart_crossover.solver_caller import solving
+        real, calls = solving.solve_lp, [0]
+
+        def flaky(*a, **k):
+            calls[0] += 1
+            if calls[0] == 2 and (single or dist.get_rank() == int(fail_rank)):
+                raise MemoryError("injected failure of the replicated solve")
+            return real(*a, **k)
+        solving.solve_lp = flaky
+        rank = 0 if single else dist.get_rank()
+        try:
+            sh.restricted_resolve(start, solver=solver, batch=batch, opt_tol=1e-7, trace=trace, **kw)
+            msg = "no exception"
+        except Exception as exc:       # noqa: BLE001
+            msg = f"{type(exc).__name__}: {exc}"
+        with open(f"{out_path}.rank{rank}", "w") as f:
+            json.dump({"raised": msg, "rounds_added": len(trace)}, f)
+        if rank == 0:
+            with open(out_path, "w") as f:
+                json.dump({"done": True}, f)
+        if not single:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     x_R, y, R, basis, status, rounds = sh.restricted_resolve(start, solver=solver, batch=batch, opt_tol=1e-7, trace=trace, **kw)
     res = {"world": 1 if single else dist.get_world_size(), "status": status, "rounds": rounds, "trace": trace,
            "obj": float(lp.c[R] @ x_R), "R": [int(j) for j in R], "basic": [int(j) for j in R[basis.vbasis == 0]]}

@@ -145,3 +145,16 @@ def test_column_sharded_re_solve_adds_the_single_process_columns(tmp_path):
         assert res["trace"] == single["trace"] and res["R"] == single["R"]
         assert res["basic"] == single["basic"]
         assert res["obj"] == pytest.approx(single["obj"], rel=1e-12)
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_sharded_resolve(tmp_path):
+    """One rank's replicated solve raises in the second round: the failure travels with the record counts, the failing rank
+    re-raises its own exception, the others a RuntimeError naming it -- and nobody waits in an all-gather (the bench's
+    `sharded_resolve` leg hung exactly so in a rehearsal)."""
+    out = tmp_path / "fail.json"
+    run_workers("_dist_worker4.py", out, 3, {"SX_TEST_BATCH": "64", "SX_TEST_FAIL_RANK": "1"})
+    msgs = [json.loads((tmp_path / f"fail.json.rank{r}").read_text()) for r in range(3)]
+    assert msgs[1]["raised"].startswith("MemoryError: injected failure")
+    for r in (0, 2):
+        assert msgs[r]["raised"].startswith("RuntimeError: restricted_resolve: rank(s) [1] left round 2")
+    assert all(m["rounds_added"] == 1 for m in msgs)
