@@ -827,11 +827,18 @@ __global__ __launch_bounds__(TB_WG) void k_tb_etab_apply(int64_t m, int64_t ncol
         }
     }
 }
-// v <- E^T v:  v[r] = (v[r] - sum_{p != r} alpha_p v[p]) / alpha_r; partial dots by G workgroups, summed in order
-__global__ __launch_bounds__(TB_WG) void k_tb_eta_t_part(int64_t m, const double *__restrict__ v, const double *__restrict__ alpha,
-                                                         const int32_t *__restrict__ eta_r, int64_t k, double *__restrict__ part) {
+// v <- E_{k0}^T ... E_{k0+K-1}^T v (the duals' way through the eta file: the youngest eta first), K <= TB_EB etas per pass.
+// One eta: v[r] <- (v[r] - sum_{p != r} alpha[p] v[p]) / alpha[r]: a dot over all positions that changes ONE entry, so the K dots
+// of a block are taken against the vector the block found (k_tb_etat_dots: one pass over the K eta columns, all workgroups busy)
+// and corrected by what the younger etas of the block changed -- a K x K triangle in one wave (k_tb_etat_solve).  One eta at a
+// time this was 2 launches and a 64-workgroup dot per eta: 80 ms per pricing round with 921 etas over 1e6 positions.
+constexpr int TB_ETS = 32; // slices of the positions per eta column (partial dots, summed in order)
+__global__ __launch_bounds__(TB_WG) void k_tb_etat_dots(int64_t m, const double *__restrict__ v, const double *__restrict__ eta,
+                                                        const int32_t *__restrict__ eta_r, int64_t k0, double *__restrict__ part) {
     __shared__ double sm[4];
+    const int64_t k = k0 + blockIdx.y;
     const int r = eta_r[k];
+    const double *alpha = eta + static_cast<size_t>(k) * m;
     double acc = 0.0;
     for (int64_t p = static_cast<int64_t>(blockIdx.x) * TB_WG + threadIdx.x; p < m; p += static_cast<int64_t>(gridDim.x) * TB_WG)
         if (p != r) {
@@ -839,14 +846,44 @@ __global__ __launch_bounds__(TB_WG) void k_tb_eta_t_part(int64_t m, const double
             if (a != 0.0) acc += a * v[p];
         }
     const double tot = tb_block_sum(acc, sm);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    if (threadIdx.x == 0) part[blockIdx.y * TB_ETS + blockIdx.x] = tot;
 }
-__global__ void k_tb_eta_t_fin(int G, double *__restrict__ v, const double *__restrict__ alpha, const int32_t *__restrict__ eta_r, int64_t k,
-                               const double *__restrict__ part) {
-    const int r = eta_r[k];
-    double t = 0.0;
-    for (int g = 0; g < G; ++g) t += part[g];
-    v[r] = (v[r] - t) / alpha[r];
+__global__ __launch_bounds__(64) void k_tb_etat_solve(int64_t m, int nslice, int K, double *__restrict__ v, const double *__restrict__ eta,
+                                                      const int32_t *__restrict__ eta_r, int64_t k0, const double *__restrict__ part) {
+    __shared__ double sM[TB_EB * TB_EB]; // sM[i][j] = alpha_i[r_j] (j > i, r_j != r_i): what step j's change adds to step i's dot
+    __shared__ int sr[TB_EB];
+    const int j = threadIdx.x;
+    sr[j] = (j < K) ? eta_r[k0 + j] : -1;
+    __syncthreads();
+    for (int e = j; e < TB_EB * TB_EB; e += 64) {
+        const int i = e / TB_EB, jj = e % TB_EB;
+        double x = 0.0;
+        if (i < K && jj < K && jj > i && sr[jj] != sr[i]) x = eta[static_cast<size_t>(k0 + i) * m + sr[jj]];
+        sM[e] = x;
+    }
+    double dot = 0.0, cur = 0.0, diag = 1.0, delta = 0.0;
+    if (j < K) {
+        for (int g = 0; g < nslice; ++g) dot += part[j * TB_ETS + g];
+        cur = v[sr[j]];
+        diag = eta[static_cast<size_t>(k0 + j) * m + sr[j]];
+    }
+    __syncthreads();
+    for (int i = K - 1; i >= 0; --i) { // lane jj holds delta of step jj (0 until it ran) and the current value at r_jj
+        double t = (j > i && j < K) ? sM[i * TB_EB + j] * delta : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        const double s_i = __shfl(dot, i, 64) + t;
+        const double cur_i = __shfl(cur, i, 64);
+        const double nw = (cur_i - s_i) / __shfl(diag, i, 64);
+        if (j == i) delta = nw - cur_i;
+        if (j <= i && sr[j] == sr[i]) cur = nw; // (older etas of the block on the same position see the new value)
+    }
+    // the value a position ends with is that of the OLDEST eta of the block on it
+    if (j < K) {
+        bool last = true;
+        for (int q = 0; q < j; ++q) last = last && (sr[q] != sr[j]);
+        if (last) v[sr[j]] = cur;
+    }
 }
 
 struct DevBufs {
@@ -1799,7 +1836,7 @@ int crossover_band_impl(sx_ctx *ctx, const sx_matrix *A, const double *b, const 
         int64_t nJ = static_cast<int64_t>(varJ.size());
         // ---------------------------------------------------------------- this epoch's blocks: positions, tableau, eta file
         const int nblk = static_cast<int>(gridof(mp));
-        double *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr, *d_vec = nullptr, *d_part = nullptr, *d_infpart = nullptr;
+        double *d_xB = nullptr, *d_lB = nullptr, *d_uB = nullptr, *d_cB = nullptr, *d_g = nullptr, *d_vec = nullptr, *d_part = nullptr, *d_infpart = nullptr, *d_etp = nullptr;
         int32_t *d_head = nullptr, *d_blist = nullptr, *d_infoff = nullptr, *d_inflist = nullptr;
         TbPart *d_rpart = nullptr;
         SX_TRY(edev.get(static_cast<size_t>(mp), &d_xB));
@@ -1810,6 +1847,7 @@ int crossover_band_impl(sx_ctx *ctx, const sx_matrix *A, const double *b, const 
         SX_TRY(edev.get(static_cast<size_t>(mp), &d_vec));
         SX_TRY(edev.get(static_cast<size_t>(mp), &d_head));
         SX_TRY(edev.get(static_cast<size_t>(2 * nblk), &d_part));
+        SX_TRY(edev.get(static_cast<size_t>(TB_EB) * TB_ETS, &d_etp));
         SX_TRY(edev.get(static_cast<size_t>(nblk), &d_blist));
         SX_TRY(edev.get(static_cast<size_t>(2 * nblk), &d_infpart));
         SX_TRY(edev.get(static_cast<size_t>(nblk), &d_infoff));
@@ -2067,11 +2105,12 @@ int crossover_band_impl(sx_ctx *ctx, const sx_matrix *A, const double *b, const 
             //      infeasibility's (g on the basic variables, nothing elsewhere)
             const bool ph1 = hst.phase == 1;
             SX_HIP(hipMemcpyAsync(d_vec, ph1 ? d_g : d_cB, sizeof(double) * static_cast<size_t>(mp), hipMemcpyDeviceToDevice, s));
-            const int etg = std::min(nblk, 64);
-            for (int64_t k = hst.n_eta - 1; k >= 0; --k) {
-                const double *al = d_eta + static_cast<size_t>(k) * mp;
-                hipLaunchKernelGGL(k_tb_eta_t_part, dim3(static_cast<unsigned>(etg)), dim3(TB_WG), 0, s, mp, d_vec, al, d_eta_r, k, d_part);
-                hipLaunchKernelGGL(k_tb_eta_t_fin, dim3(1), dim3(1), 0, s, etg, d_vec, al, d_eta_r, k, d_part);
+            const int ets = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(TB_ETS, mp / 8192)));
+            for (int64_t hi = hst.n_eta; hi > 0; hi -= TB_EB) { // blocks of TB_EB etas, the youngest first
+                const int64_t k0 = std::max<int64_t>(0, hi - TB_EB);
+                const int K = static_cast<int>(hi - k0);
+                hipLaunchKernelGGL(k_tb_etat_dots, dim3(static_cast<unsigned>(ets), static_cast<unsigned>(K)), dim3(TB_WG), 0, s, mp, d_vec, d_eta, d_eta_r, k0, d_etp);
+                hipLaunchKernelGGL(k_tb_etat_solve, dim3(1), dim3(64), 0, s, mp, ets, K, d_vec, d_eta, d_eta_r, k0, d_etp);
             }
             SX_TRY(ops.btran(d_vec)); // B_aug^T y = v: position space in, row space out
             std::vector<double> yeq;
