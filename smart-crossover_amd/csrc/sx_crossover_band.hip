@@ -742,7 +742,7 @@ __global__ __launch_bounds__(TB_WG) void k_tb_post(int64_t nJ, double *__restric
 // sigma_i = (w0[r_i] - sum_{j<i} u_j[r_i] sigma_j) / alpha_i[r_i] (a K x K triangle per column), then W <- W - U Sigma in
 // ONE pass over W instead of K (applying 8,214 etas to 373 columns one eta at a time moved 9 GB per eta: 16.5 s).
 constexpr int TB_EB = 64; // etas per block
-constexpr int TB_EC = 16; // columns per workgroup of the rank-K pass
+constexpr int TB_EC = 64; // columns per workgroup of the rank-K pass (16: the eta block was re-read once per 16 columns -- 12 GB of a 18 GB pass at 1e6 rows x 373 columns)
 __global__ __launch_bounds__(TB_WG) void k_tb_etab_gather(int64_t m, int64_t ncols, const double *__restrict__ W, const double *__restrict__ eta,
                                                           const int32_t *__restrict__ eta_r, int64_t k0, int K, double *__restrict__ G,
                                                           double *__restrict__ M) {
