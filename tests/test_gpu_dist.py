@@ -77,12 +77,16 @@ def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
     env["SX_BENCH_REHEARSAL"] = "rccl1"
     dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py")]
-                          + common + ["--cg-iters", "5"], env=env, capture_output=True, timeout=600, cwd=root)
+                          + common + ["--cg-iters", "5", "--resolve-rows", "4000"], env=env, capture_output=True, timeout=600, cwd=root)
     assert dist.returncode == 0, dist.stderr.decode(errors="replace")[-2000:]
     a = json.loads(plain.stdout.decode().strip().splitlines()[-1])
     b = json.loads(dist.stdout.decode().strip().splitlines()[-1])
     assert a["result"] == b["result"] and b["result"]["fix_low"] > 0
     assert b["n_gpus"] == 1 and b["sharded_cg"]["iterations"] == 5
+    # the column-sharded re-solve leg went over RCCL too (record counts, records, entering columns) and reached the optimum
+    rs = b["sharded_resolve"]
+    assert "failed" not in rs, rs
+    assert rs["status"] == "OPTIMAL" and rs["rounds"] >= 2 and sum(rs["columns_added"]) > 0
 
 
 def test_column_sharded_re_solve_on_the_device(tmp_path):
