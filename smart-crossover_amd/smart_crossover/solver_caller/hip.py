@@ -196,8 +196,9 @@ class HipCaller(SolverCaller):
             if (to_band and mode == "auto" and m < 200_000 and self._warm_point is not None
                     and np.asarray(self._warm_point[0]).size == n):
                 # the dense crossover needs the full first-order budget in front of it: ask the sparse one now whether it
-                # will take this LP (its matching on the point at hand: ~20 ms at 1e5 rows; at 1e6 rows the question costs
-                # 0.2 s and is not asked -- a refusal there lets the first-order stage go on to the full budget instead)
+                # will take this LP (one kernel when no column of A is taller than a band the LU takes; else its matching on
+                # the point at hand: ~20 ms at 1e5 rows; at 1e6 rows the question is not asked -- a refusal there lets the
+                # first-order stage go on to the full budget instead)
                 x_probe = put(np.clip(np.asarray(self._warm_point[0], dtype=np.float64), self._l, self._u))
                 to_band = ctx.crossover_band_takes(dA, d_b, d_c, d_l, d_u, ctx.to_device(self._row_lt), x_probe)
             iters = int(os.environ.get("SX_PDLP_ITERS", _pdlp_iterations(m, to_band)))
