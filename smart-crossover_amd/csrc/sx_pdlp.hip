@@ -520,7 +520,9 @@ SX_API int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const d
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool use_graph = ctx->opt_graph != 0 && getenv("SX_NO_GRAPH") == nullptr &&
-                     getenv("ROCP_TOOL_LIBRARIES") == nullptr; // (rocprofv3 --kernel-trace faults on graph replay: profiles/r03/hipgraph_rocprofv3.md)
+                     (getenv("ROCP_TOOL_LIBRARIES") == nullptr || getenv("SX_GRAPH_UNDER_PROFILER") != nullptr);
+    // (rocprofv3 --kernel-trace faults on graph replay: profiles/r03/hipgraph_rocprofv3.md, frames named in profiles/r04/hipgraph_frames.md;
+    //  SX_GRAPH_UNDER_PROFILER=1 keeps the graph path there -- to reproduce the fault, not to measure)
     if (use_graph) {
         SX_HIP(hipStreamSynchronize(s));
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -543,7 +545,7 @@ SX_API int sx_pdlp_dev(sx_ctx *ctx, const sx_matrix *A, const double *b, const d
         }
     } gguard{graph, exec};
     const int64_t periods = max_iter / PD_PERIOD;
-    const int poll = 8;
+    const int poll = getenv("SX_PDLP_POLL") ? std::max(1, atoi(getenv("SX_PDLP_POLL"))) : 8; // periods enqueued between two looks at the state
     for (int64_t p = 0; p < periods;) {
         const int64_t upto = std::min<int64_t>(p + poll, periods);
         for (; p < upto; ++p) {

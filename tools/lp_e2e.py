@@ -45,6 +45,9 @@ def main():
     caller = solving.generate_solver_caller("HIP", SolverSettings(presolve="on", log_console=0))
     caller.read_genlp(mgr.lp_sub)
     caller.add_warm_start_solution((mgr.get_subx(inst.x), inst.y))
+    if os.environ.get("SX_DUMP_MAPS"):     # (to name the frames of a native fault in the re-solve: profiles/r04/hipgraph_frames.md)
+        with open(os.environ["SX_DUMP_MAPS"], "w") as f:
+            f.write(open("/proc/self/maps").read())
     with redirect_stdout(io.StringIO()):
         caller.run_barrier()
         out = caller.return_output()
